@@ -1,0 +1,124 @@
+"""CPU tests that pin the oracle (no GPU): known answers of the reference's notebook, fixtures,
+NumPy restatement vs torch-autograd twin vs finite differences, natgrad closed form."""
+import numpy as np
+import pytest
+
+import dgp_oracle as O
+import dgp_oracle_torch as T
+from helpers import CASES, load, n_layers, notebook_data, oracle_from_golden
+
+
+def test_notebook_known_answers():
+    """nb_DGP_regression.ipynb cells 22/26 (first ELBO line) and cell 30."""
+    X, Y, Z = notebook_data()
+    g = load("notebook_known_answer")
+    np.testing.assert_array_equal(X, g["X"])
+    np.testing.assert_array_equal(Y, g["Y"])
+    kernels = [O.RBF(1.0, [1.0] * u) for u in [1, 1, 1]]
+    m = O.OracleDGP(X, Y, Z, kernels, [1, 1], num_samples=10)
+    for seed in (0, 1, 2):                      # z-independent at construction
+        elbo = m.ELBO(O.draw_zs(m, seed, 10, 50))
+        assert abs(elbo - (-85.98812279560475)) < 1e-9
+    assert m.number_parameters() == 2032
+    # torch twin agrees, and so does its closed form  sum_n[-0.5 log 2pi - 0.5 (y^2 + 1)]
+    et, _ = T.elbo_and_grads(m, O.draw_zs(m, 0, 10, 50), want_grads=False)
+    assert abs(et - (-85.98812279560475)) < 1e-9
+    closed = np.sum(-0.5 * np.log(2 * np.pi) - 0.5 * (Y ** 2 + 1.0))
+    assert abs(closed - (-85.98812279560475)) < 1e-10
+
+
+def test_q_sqrt_scaling_known_value():
+    """with the q_sqrt*1e-3 line (dgp.py:268-269) each inner layer adds KL = 160.19."""
+    X, Y, Z = notebook_data()
+    m = O.OracleDGP(X, Y, Z, [O.RBF(1.0, [1.0]) for _ in range(3)], [1, 1], num_samples=10)
+    for l in m.layers[:-1]:
+        l.q_sqrt = l.q_sqrt * 1e-3
+        kl = l.KL()
+        assert abs(kl - (25 * np.log(1e3) - 12.5 + 12.5e-6)) < 1e-6
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_golden_forward_and_elbo(case):
+    g = load(case)
+    m = oracle_from_golden(g)
+    zs = [g[f"zs{i}"] for i in range(n_layers(g))]
+    Fs, Fm, Fv = m.propagate(g["X"], int(g["S"]), zs)
+    for i in range(n_layers(g)):
+        np.testing.assert_allclose(Fs[i], g[f"Fs{i}"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(Fm[i], g[f"Fmeans{i}"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(Fv[i], g[f"Fvars{i}"], rtol=1e-12, atol=1e-12)
+    assert abs(m.ELBO(zs) - g["elbo"]) < 1e-9
+    assert [l.mean_function.kind for l in m.layers] == [str(g[f"L{i}_mean_kind"]) for i in range(n_layers(g))]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_torch_twin_matches_and_gradients_by_finite_differences(case):
+    g = load(case)
+    m = oracle_from_golden(g)
+    zs = [g[f"zs{i}"] for i in range(n_layers(g))]
+    elbo, G = T.elbo_and_grads(m, zs)
+    assert abs(elbo - g["elbo"]) < 1e-9
+    elbo_c, Gc = T.elbo_and_grads(m, zs, chunk=17)            # chunking is numerically neutral
+    assert abs(elbo_c - elbo) < 1e-9
+    for i in range(n_layers(g)):
+        for k in ("Z", "variance", "lengthscales", "q_mu", "q_sqrt"):
+            np.testing.assert_allclose(G["layers"][i][k], g[f"g_L{i}_{k}"], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(Gc["layers"][i][k], G["layers"][i][k], rtol=1e-8, atol=1e-8)
+    h = 1e-6
+
+    def fd(setter):
+        setter(+h); ep = m.ELBO(zs); setter(-2 * h); em = m.ELBO(zs); setter(+h)
+        return (ep - em) / (2 * h)
+
+    for i, l in enumerate(m.layers):
+        def sz(d, l=l): l.Z[1, 0] += d
+        def sl(d, l=l): l.kern.lengthscales[0] += d
+        def sv(d, l=l): l.kern.variance += d
+        def sm(d, l=l): l.q_mu[2, 0] += d
+        def sq(d, l=l): l.q_sqrt[0, 3, 1] += d
+        for setter, val in ((sz, G["layers"][i]["Z"][1, 0]), (sl, G["layers"][i]["lengthscales"][0]),
+                            (sv, G["layers"][i]["variance"]), (sm, G["layers"][i]["q_mu"][2, 0]),
+                            (sq, G["layers"][i]["q_sqrt"][0, 3, 1])):
+            assert abs(fd(setter) - val) < 2e-5 * max(1.0, abs(val))
+
+    def slv(d): m.lik_variance += d
+    assert abs(fd(slv) - G["lik_variance"]) < 2e-5 * max(1.0, abs(G["lik_variance"]))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_natgrad_closed_form_equals_gpflow_autodiff_route(case):
+    g = load(case)
+    m = oracle_from_golden(g)
+    for i, l in enumerate(m.layers):
+        a = O.natgrad_step(l.q_mu, l.q_sqrt, -g[f"g_L{i}_q_mu"], -g[f"g_L{i}_q_sqrt"], float(g["natgrad_gamma"]))
+        b = T.natgrad_step_autodiff(l.q_mu, l.q_sqrt, -g[f"g_L{i}_q_mu"], -g[f"g_L{i}_q_sqrt"],
+                                    float(g["natgrad_gamma"]))
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-8, atol=1e-9)      # two routes, cond(Kuu) ~ 1e6
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(a[0], g[f"ng_L{i}_q_mu"], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(a[1], g[f"ng_L{i}_q_sqrt"], rtol=1e-10, atol=1e-11)
+
+
+def test_philox_normals_are_standard_and_index_keyed():
+    z = O.philox_normal(3, 1, 4, np.arange(20000), 2)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    # keyed by the global point index: a shard sees exactly the slice of the full draw
+    zs = O.philox_normal(3, 1, 4, np.arange(5000, 7000), 2)
+    np.testing.assert_array_equal(zs, z[:, 5000:7000])
+    # known-answer of Philox4x32-10 (Random123 kat_vectors: counter=key=0)
+    r = O.philox4x32_10(0, 0, 0, 0, 0, 0)
+    assert [int(x) for x in r] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+
+
+def test_layer_init_mean_functions():
+    """layer_initializations.py:41-61: identity / PCA step-down / zero-pad step-up."""
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((40, 3)); Y = rng.standard_normal((40, 1)); Z = X[:7].copy()
+    m = O.OracleDGP(X, Y, Z, [O.RBF(1.0, np.ones(d)) for d in (3, 2, 4)], [2, 4])
+    kinds = [l.mean_function.kind for l in m.layers]
+    assert kinds == ["linear", "linear", "zero"]
+    _, _, V = np.linalg.svd(X, full_matrices=False)
+    np.testing.assert_allclose(m.layers[0].mean_function.A, V[:2].T)
+    np.testing.assert_array_equal(m.layers[1].mean_function.A, np.eye(2, 4))
+    np.testing.assert_allclose(m.layers[1].Z, Z @ V[:2].T)
+    np.testing.assert_allclose(m.layers[2].Z, Z @ V[:2].T @ np.eye(2, 4))
