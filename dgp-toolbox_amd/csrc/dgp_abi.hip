@@ -1,0 +1,969 @@
+// libdgp_hip.so: context, orchestration of the SVGP-layer ELBO path and the C-ABI (include/dgp_abi.h).
+//
+// Reference path being replaced (all executed by TensorFlow/GPflow there):
+//   DGP_Base.propagate / ELBO            dgp_dace/models/dgp.py:34-109
+//   SVGP_Layer.conditional_ND / KL        dgp_dace/utils/layers.py:227-308
+//   Layer.sample_from_conditional         dgp_dace/utils/layers.py:87-130, utils.py:22-51
+//   DGP.optimize_adam / optimize_nat_adam dgp_dace/models/dgp.py:255-345 (loop bodies)
+//
+// Whitened formulation used on the device (identical in exact arithmetic to layers.py:243-276):
+//   Lu = chol(K(Z,Z) + 1e-6 I),  c_p = Lu^-1 k(Z, x_p),  W_d = Lu^-1 L_q,d (non-white) or L_q,d (white),
+//   u = Lu^-1 q_mu (non-white) or q_mu,   mean = c^T u + mf(x),   var = k_diag - |c|^2 + |W_d^T c|^2.
+// Data layout in HBM: every per-point intermediate is point-major ([points][M] / [points][D][M]), so
+// a tile of points is one contiguous slab; a chunk of data points (all S samples of each point) goes
+// through forward-all-layers then backward-all-layers with its intermediates resident in HBM.
+#include "../../include/dgp_abi.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dgp_internal.h"
+
+using namespace dgp;
+
+namespace {
+
+struct Layer {
+  dgp_layer_desc d;
+  int Mp;
+  long off_Z, off_var, off_ls, off_qmu, off_qsqrt;   // offsets in the flat parameter vector
+  double *meanW = nullptr, *meanb = nullptr;
+  double *Kuu, *Lu, *Linv, *Lq, *qmu_p, *Wcat, *u;   // derived small matrices (padded to Mp)
+  double *dLq, *dqmu_p;                              // d ELBO / d (Lq, q_mu) of the last grad_finish
+  long acc_Q, acc_dW, acc_du, acc_dZ, acc_dls, acc_dvar;
+  double *Kt, *Ct, *Tt, *mean, *var, *F, *mbar, *vbar;   // chunk workspace
+};
+
+constexpr int kNCat = 4;
+struct Prof {
+  bool on = false;
+  int depth = 0;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> cat;
+  size_t used = 0;
+  double ms[kNCat] = {0, 0, 0, 0}, flops[kNCat] = {0, 0, 0, 0}, bytes[kNCat] = {0, 0, 0, 0};
+  long launches[kNCat] = {0, 0, 0, 0};
+};
+
+}  // namespace
+
+struct dgp_ctx {
+  int device = 0;
+  hipStream_t st = nullptr;
+  bool own_stream = false;
+  std::string err;
+  std::vector<Layer> L;
+  long n_params = 0;
+  double *params = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  long adam_t = 0;
+  std::vector<ParamSeg> segs;
+  ParamSeg* segs_dev = nullptr;
+  double *mean_params = nullptr;
+  double *X = nullptr, *Y = nullptr;
+  long N = 0;
+  int D = 0, Dy = 0;
+  long n_goff = 0;
+  double *acc = nullptr, *acc_own = nullptr;
+  long n_acc = 0;
+  double* scal = nullptr;   // device scalars: [0] sum KL, [1] ELBO of last grad_finish, [2] scratch data term
+  int* info = nullptr;
+  char* ws = nullptr;
+  size_t ws_cap = 0;
+  long ws_limit = 96L << 30;
+  double *Cbar = nullptr, *Kbar = nullptr, *xbar = nullptr;
+  double* sm[10] = {nullptr};
+  std::vector<double*> zs_dev;
+  std::vector<size_t> zs_cap;
+  double* Xnew = nullptr;
+  size_t Xnew_cap = 0;
+  std::vector<double*> out_dev[3];
+  std::vector<size_t> out_cap[3];
+  bool grad_ready = false;
+  bool segs_uploaded = false;
+  Prof prof;
+};
+
+namespace {
+
+int fail(dgp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[512];
+  if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  else snprintf(buf, sizeof buf, "%s", what);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define HIPCHK(x)                                                   \
+  do {                                                              \
+    hipError_t e_ = (x);                                            \
+    if (e_ != hipSuccess) return fail(ctx, DGP_ERR_HIP, #x, e_);    \
+  } while (0)
+#define RET(x)                  \
+  do {                          \
+    int r_ = (x);               \
+    if (r_ != DGP_OK) return r_; \
+  } while (0)
+
+inline long round_up(long x, long m) { return ((x + m - 1) / m) * m; }
+
+// ------------------------------------------------------------------------------- profiling helpers
+int prof_drain(dgp_ctx* ctx) {
+  Prof& p = ctx->prof;
+  if (p.used == 0) return DGP_OK;
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  for (size_t i = 0; i < p.used; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
+    p.ms[p.cat[i]] += ms;
+  }
+  p.used = 0;
+  return DGP_OK;
+}
+
+struct ProfScope {
+  dgp_ctx* ctx;
+  bool active;
+  size_t slot;
+  ProfScope(dgp_ctx* c, int cat, double flops, double bytes) : ctx(c), active(false), slot(0) {
+    Prof& p = c->prof;
+    if (!p.on) return;
+    p.flops[cat] += flops;
+    p.bytes[cat] += bytes;
+    if (p.depth++ > 0) return;          // nested scopes are covered by the outermost one
+    active = true;
+    if (p.used * 2 + 2 > p.ev.size()) {
+      if (p.ev.size() < 2 * 8192) {
+        const size_t old = p.ev.size();
+        p.ev.resize(old + 1024);
+        for (size_t i = old; i < p.ev.size(); ++i) (void)hipEventCreate(&p.ev[i]);
+        p.cat.resize(p.ev.size() / 2);
+      } else {
+        prof_drain(c);
+      }
+    }
+    slot = p.used++;
+    p.cat[slot] = cat;
+    p.launches[cat] += 1;
+    (void)hipEventRecord(p.ev[2 * slot], c->st);
+  }
+  ~ProfScope() {
+    Prof& p = ctx->prof;
+    if (!p.on) return;
+    if (active) (void)hipEventRecord(p.ev[2 * slot + 1], ctx->st);
+    if (p.depth > 0) --p.depth;
+  }
+};
+
+// ------------------------------------------------------------------------------- GEMM wrapper
+int G(dgp_ctx* ctx, int cat, GemmOp op, long M, long N, long K, const double* A, long lda, const double* B, long ldb,
+      double* C, long ldc, double alpha, int beta, int batch = 1, long sA = 0, long sB = 0, long sC = 0,
+      int splits = 1, int tri = TRI_NONE, long triblk = 0, double flops = 0.0, double bytes = 0.0) {
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.M = M; a.N = N; a.K = K;
+  a.sA = sA; a.sB = sB; a.sC = sC;
+  a.batch = batch; a.splits = splits; a.ksplit = 0;
+  a.alpha = alpha; a.beta = beta; a.tri = tri; a.triblk = triblk;
+  if (M <= 0 || N <= 0 || K <= 0) return DGP_OK;
+  ProfScope ps(ctx, cat, flops, bytes);
+  HIPCHK(gemm_f64(ctx->st, op, a));
+  return DGP_OK;
+}
+
+int pick_splits(long Mrows, long Ncols, long K) {
+  const long tiles = ((Mrows + 127) / 128) * ((Ncols + 127) / 128);
+  long s = 1536 / (tiles > 0 ? tiles : 1);
+  const long kmax = K / 512;
+  if (s > kmax) s = kmax;
+  if (s < 1) s = 1;
+  if (s > 1024) s = 1024;
+  return (int)s;
+}
+
+// ------------------------------------------------------------------------------- memory helpers
+template <typename T>
+int dev_alloc(dgp_ctx* ctx, T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  return DGP_OK;
+}
+template <typename T>
+void dev_free(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+int grow(dgp_ctx* ctx, double** p, size_t* cap, size_t n) {
+  if (*cap >= n && *p) return DGP_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  RET(dev_alloc(ctx, p, n));
+  *cap = n;
+  return DGP_OK;
+}
+
+void free_model(dgp_ctx* ctx) {
+  for (auto& l : ctx->L) {
+    dev_free(l.Kuu); dev_free(l.Lu); dev_free(l.Linv); dev_free(l.Lq); dev_free(l.qmu_p); dev_free(l.Wcat);
+    dev_free(l.u); dev_free(l.dLq); dev_free(l.dqmu_p);
+  }
+  ctx->L.clear();
+  dev_free(ctx->params); dev_free(ctx->grad); dev_free(ctx->adam_m); dev_free(ctx->adam_v);
+  dev_free(ctx->segs_dev); dev_free(ctx->mean_params); dev_free(ctx->acc_own);
+  ctx->acc = nullptr;
+  for (auto& s : ctx->sm) dev_free(s);
+  for (auto& z : ctx->zs_dev) dev_free(z);
+  ctx->zs_dev.clear(); ctx->zs_cap.clear();
+  for (int k = 0; k < 3; ++k) {
+    for (auto& o : ctx->out_dev[k]) dev_free(o);
+    ctx->out_dev[k].clear(); ctx->out_cap[k].clear();
+  }
+  ctx->n_params = 0;
+  ctx->grad_ready = false;
+  ctx->segs_uploaded = false;
+}
+
+// carve the chunk workspace; returns bytes needed.  base == nullptr: size query only
+size_t carve(dgp_ctx* ctx, char* base, long Nc, int S, bool train) {
+  size_t off = 0;
+  auto take = [&](long nd) -> double* {
+    double* p = base ? reinterpret_cast<double*>(base + off) : nullptr;
+    off += (size_t)round_up(nd * 8, 256);
+    return p;
+  };
+  const int nl = (int)ctx->L.size();
+  long Pmax_Mp = 0, T_max = 0, xb_max = 0;
+  for (int l = 0; l < nl; ++l) {
+    Layer& y = ctx->L[l];
+    const long Pl = (l == 0) ? Nc : (long)S * Nc;
+    Pmax_Mp = std::max(Pmax_Mp, Pl * y.Mp);
+    T_max = std::max(T_max, Pl * y.d.D_out * y.Mp);
+    xb_max = std::max(xb_max, (long)S * Nc * y.d.D_in);
+  }
+  double *sKt = nullptr, *sCt = nullptr, *sTt = nullptr;
+  if (!train) { sKt = take(Pmax_Mp); sCt = take(Pmax_Mp); sTt = take(T_max); }
+  for (int l = 0; l < nl; ++l) {
+    Layer& y = ctx->L[l];
+    const long Pl = (l == 0) ? Nc : (long)S * Nc;
+    const long D = y.d.D_out;
+    if (train) { y.Kt = take(Pl * y.Mp); y.Ct = take(Pl * y.Mp); y.Tt = take(Pl * D * y.Mp); }
+    else { y.Kt = sKt; y.Ct = sCt; y.Tt = sTt; }
+    y.mean = take(Pl * D); y.var = take(Pl * D);
+    y.F = take((long)S * Nc * D);
+    if (train) { y.mbar = take(Pl * D); y.vbar = take(Pl * D); }
+    else { y.mbar = y.vbar = nullptr; }
+  }
+  if (train) { ctx->Cbar = take(Pmax_Mp); ctx->Kbar = take(Pmax_Mp); ctx->xbar = take(xb_max); }
+  return off;
+}
+
+int ensure_ws(dgp_ctx* ctx, long N, int S, bool train, long* Nc_out) {
+  const size_t per1 = carve(ctx, nullptr, 1024, S, train) / 1024 + 1;
+  long Nc = (long)((size_t)ctx->ws_limit / per1);
+  if (Nc < 1) Nc = 1;
+  if (Nc > N) Nc = N;
+  size_t need = carve(ctx, nullptr, Nc, S, train);
+  while (need > (size_t)ctx->ws_limit && Nc > 1) { Nc = Nc * 9 / 10; need = carve(ctx, nullptr, Nc, S, train); }
+  if (need > ctx->ws_cap) {
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    ctx->ws = nullptr; ctx->ws_cap = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&ctx->ws), need));
+    ctx->ws_cap = need;
+  }
+  carve(ctx, ctx->ws, Nc, S, train);
+  *Nc_out = Nc;
+  return DGP_OK;
+}
+
+int upload_zs(dgp_ctx* ctx, const double* const* zs, int S, long Ntot) {
+  const int nl = (int)ctx->L.size();
+  if ((int)ctx->zs_dev.size() < nl) { ctx->zs_dev.resize(nl, nullptr); ctx->zs_cap.resize(nl, 0); }
+  for (int l = 0; l < nl; ++l) {
+    if (!zs[l]) return fail(ctx, DGP_ERR_INVALID, "zs: NULL entry");
+    const size_t n = (size_t)S * Ntot * ctx->L[l].d.D_out;
+    RET(grow(ctx, &ctx->zs_dev[l], &ctx->zs_cap[l], n));
+    HIPCHK(hipMemcpyAsync(ctx->zs_dev[l], zs[l], n * 8, hipMemcpyHostToDevice, ctx->st));
+  }
+  return DGP_OK;
+}
+
+inline const double* P(dgp_ctx* ctx, long off) { return ctx->params + off; }
+
+// ------------------------------------------------------------------------------- prep: small matrices + KL
+int prep(dgp_ctx* ctx) {
+  HIPCHK(hipMemsetAsync(ctx->scal, 0, 4 * sizeof(double), ctx->st));
+  for (auto& y : ctx->L) {
+    const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
+    const long MM = (long)Mp * Mp;
+    ProfScope ps(ctx, 2, 0, 0);
+    HIPCHK(pack_q(ctx->st, P(ctx, y.off_qsqrt), P(ctx, y.off_qmu), M, Mp, D, y.Lq, y.qmu_p));
+    HIPCHK(rbf_kuu(ctx->st, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din, y.Kuu));
+    HIPCHK(copy_mat(ctx->st, y.Kuu, y.Lu, MM));
+    HIPCHK(chol_lower(ctx->st, y.Lu, Mp, 1, ctx->info));
+    HIPCHK(trinv_lower(ctx->st, y.Lu, y.Linv, Mp, 1));
+    if (y.d.white) {
+      HIPCHK(lq_to_wcat(ctx->st, y.Lq, Mp, D, y.Wcat));
+      HIPCHK(copy_mat(ctx->st, y.qmu_p, y.u, (long)Mp * D));
+    } else {
+      RET(G(ctx, 2, GEMM_NN, Mp, Mp, Mp, y.Linv, Mp, y.Lq, Mp, y.Wcat, (long)D * Mp, 1.0, 0, D, 0, MM, Mp));
+      RET(G(ctx, 2, GEMM_NN, Mp, D, Mp, y.Linv, Mp, y.qmu_p, D, y.u, D, 1.0, 0));
+    }
+    HIPCHK(layer_kl(ctx->st, y.Wcat, y.u, y.Lq, y.Lu, M, Mp, D, y.d.white, ctx->scal));
+  }
+  return DGP_OK;
+}
+
+ZSource zsrc_of(dgp_ctx* ctx, int l, bool use_zs, uint64_t seed, long n_goff, long Ntot) {
+  ZSource z;
+  z.zs = use_zs ? ctx->zs_dev[l] : nullptr;
+  z.seed = seed;
+  z.layer = l;
+  z.n_global0 = n_goff;
+  z.Ntot = Ntot;
+  return z;
+}
+
+// ------------------------------------------------------------------------------- forward over one chunk
+int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc, int S, uint64_t seed, bool use_zs,
+                  long n_goff) {
+  const int nl = (int)ctx->L.size();
+  for (int l = 0; l < nl; ++l) {
+    Layer& y = ctx->L[l];
+    const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
+    const bool dedup = (l == 0);
+    const long Pl = dedup ? Nc : (long)S * Nc;
+    const double* Xin = dedup ? Xsrc : ctx->L[l - 1].F;
+    const long row0 = dedup ? n0 : 0;
+    {
+      ProfScope ps(ctx, 1, 0, (double)Pl * (Mp + Din) * 8);
+      HIPCHK(rbf_kuf(ctx->st, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din, y.Kt));
+    }
+    const double tri1 = (double)Pl * Mp * (Mp + 1.0);   // 2 * M(M+1)/2 flops per point
+    RET(G(ctx, 0, GEMM_NT, Pl, Mp, Mp, y.Kt, Mp, y.Linv, Mp, y.Ct, Mp, 1.0, 0, 1, 0, 0, 0, 1, TRI_B_UPPER, Mp, tri1,
+          (double)Pl * Mp * 16));
+    RET(G(ctx, 0, GEMM_NN, Pl, (long)D * Mp, Mp, y.Ct, Mp, y.Wcat, (long)D * Mp, y.Tt, (long)D * Mp, 1.0, 0, 1, 0, 0, 0,
+          1, TRI_B_LOWER, Mp, tri1 * D, (double)Pl * Mp * 8 * (1 + D)));
+    {
+      ProfScope ps(ctx, 1, 0, (double)Pl * Mp * 8 * (1 + D));
+      const bool last = (l == nl - 1);
+      (void)last;
+      HIPCHK(var_mean_sample(ctx->st, y.Ct, y.Tt, y.u, Xin, row0, Pl, Nc, S, dedup ? 1 : 0, M, Mp, Din, D,
+                             P(ctx, y.off_var), y.d.mean_kind, y.meanW, y.meanb,
+                             zsrc_of(ctx, l, use_zs, seed, n_goff, Ntot), n0, y.mean, y.var, y.F));
+    }
+  }
+  return DGP_OK;
+}
+
+// ------------------------------------------------------------------------------- backward over one chunk
+int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool use_zs) {
+  const int nl = (int)ctx->L.size();
+  double* acc = ctx->acc;
+  for (int l = nl - 1; l >= 0; --l) {
+    Layer& y = ctx->L[l];
+    const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
+    const bool dedup = (l == 0);
+    const long Pl = dedup ? Nc : (long)S * Nc;
+    const double* Xin = dedup ? ctx->X : ctx->L[l - 1].F;
+    const long row0 = dedup ? n0 : 0;
+    const long DM = (long)D * Mp;
+    const double tri1 = (double)Pl * Mp * (Mp + 1.0);
+    {
+      ProfScope ps(ctx, 1, 0, (double)Pl * DM * 16);
+      HIPCHK(scale_T(ctx->st, y.Tt, y.vbar, Pl, Mp, D));
+    }
+    RET(G(ctx, 0, GEMM_NT, Pl, Mp, DM, y.Tt, DM, y.Wcat, DM, ctx->Cbar, Mp, 1.0, 0, 1, 0, 0, 0, 1, TRI_B_UPPER, Mp,
+          tri1 * D, (double)Pl * Mp * 8 * (1 + D)));
+    {
+      ProfScope ps(ctx, 1, 0, (double)Pl * Mp * 24);
+      HIPCHK(cbar_fix(ctx->st, ctx->Cbar, y.Ct, y.mbar, y.vbar, y.u, Pl, Mp, D));
+    }
+    RET(G(ctx, 0, GEMM_NN, Pl, Mp, Mp, ctx->Cbar, Mp, y.Linv, Mp, ctx->Kbar, Mp, 1.0, 0, 1, 0, 0, 0, 1, TRI_B_LOWER, Mp,
+          tri1, (double)Pl * Mp * 16));
+    // reductions over the chunk's points (accumulate into the all-reduce buffer)
+    RET(G(ctx, 0, GEMM_TN, Mp, DM, Pl, y.Ct, Mp, y.Tt, DM, acc + y.acc_dW, DM, 1.0, 1, 1, 0, 0, 0,
+          pick_splits(Mp, DM, Pl), TRI_OUT_LOWER, Mp, tri1 * D, (double)Pl * Mp * 8 * (1 + D)));
+    RET(G(ctx, 0, GEMM_TN, Mp, Mp, Pl, ctx->Kbar, Mp, y.Ct, Mp, acc + y.acc_Q, Mp, 1.0, 1, 1, 0, 0, 0,
+          pick_splits(Mp, Mp, Pl), TRI_OUT_LOWER, Mp, tri1, (double)Pl * Mp * 16));
+    RET(G(ctx, 0, GEMM_TN, Mp, D, Pl, y.Ct, Mp, y.mbar, D, acc + y.acc_du, D, 1.0, 1, 1, 0, 0, 0,
+          pick_splits(Mp, D, Pl), TRI_NONE, 0, 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
+    {
+      ProfScope ps(ctx, 1, 0, (double)Pl * Mp * 16);
+      HIPCHK(rbf_kuf_bwd(ctx->st, ctx->Kbar, y.Kt, Xin, row0, Pl, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls),
+                         M, Mp, Din, D, y.d.mean_kind, y.meanW, y.mbar, l > 0 ? 1 : 0, ctx->xbar, acc + y.acc_dZ,
+                         acc + y.acc_dls, acc + y.acc_dvar));
+    }
+    if (l > 0) {
+      Layer& w = ctx->L[l - 1];
+      ProfScope ps(ctx, 1, 0, (double)S * Nc * Din * 24);
+      HIPCHK(fold_sample_grad(ctx->st, ctx->xbar, w.var, Nc, S, (l - 1 == 0) ? 1 : 0, w.d.D_out,
+                              zsrc_of(ctx, l - 1, use_zs, seed, ctx->n_goff, ctx->N), n0, w.mbar, w.vbar,
+                              acc + w.acc_dvar));
+    }
+  }
+  return DGP_OK;
+}
+
+int check_flags(dgp_ctx* ctx) {
+  int h = 0;
+  HIPCHK(hipMemcpyAsync(&h, ctx->info, sizeof(int), hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  if (h) {
+    HIPCHK(hipMemsetAsync(ctx->info, 0, sizeof(int), ctx->st));
+    return fail(ctx, DGP_ERR_NOT_PD, "Cholesky: matrix is not positive definite");
+  }
+  return DGP_OK;
+}
+
+}  // namespace
+
+// =================================================================================== C-ABI
+extern "C" {
+
+int dgp_create(int device, void* hip_stream, dgp_ctx** out) {
+  if (!out) return DGP_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return DGP_ERR_NO_DEVICE;
+  dgp_ctx* ctx = new dgp_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete ctx; return DGP_ERR_NO_DEVICE; }
+  if (hip_stream) ctx->st = reinterpret_cast<hipStream_t>(hip_stream);
+  else {
+    if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess) { delete ctx; return DGP_ERR_HIP; }
+    ctx->own_stream = true;
+  }
+  if (hipMalloc(reinterpret_cast<void**>(&ctx->scal), 4 * sizeof(double)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&ctx->info), sizeof(int)) != hipSuccess) {
+    delete ctx;
+    return DGP_ERR_HIP;
+  }
+  (void)hipMemset(ctx->info, 0, sizeof(int));
+  (void)hipMemset(ctx->scal, 0, 4 * sizeof(double));
+  *out = ctx;
+  return DGP_OK;
+}
+
+void dgp_destroy(dgp_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->st);
+  free_model(ctx);
+  dev_free(ctx->X); dev_free(ctx->Y); dev_free(ctx->scal); dev_free(ctx->info); dev_free(ctx->Xnew);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  for (auto e : ctx->prof.ev) (void)hipEventDestroy(e);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->st);
+  delete ctx;
+}
+
+const char* dgp_last_error(const dgp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int dgp_sync(dgp_ctx* ctx) {
+  if (!ctx) return DGP_ERR_INVALID;
+  return check_flags(ctx);
+}
+
+int dgp_device_info(dgp_ctx* ctx, char* name_out, int name_len, int* cu_count, int64_t* hbm_bytes) {
+  if (!ctx) return DGP_ERR_INVALID;
+  hipDeviceProp_t p;
+  HIPCHK(hipGetDeviceProperties(&p, ctx->device));
+  if (name_out && name_len > 0) snprintf(name_out, name_len, "%s (%s)", p.name, p.gcnArchName);
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+  return DGP_OK;
+}
+
+int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, const double* flat_params, int64_t n_params,
+                  const double* mean_params, int64_t n_mean_params) {
+  if (!ctx || n_layers <= 0 || !layers || !flat_params) return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  free_model(ctx);
+  long off = 0, moff = 0, aoff = 4;
+  int Mpmax = 0, Dmax = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    const dgp_layer_desc& d = layers[l];
+    if (d.D_in <= 0 || d.D_out <= 0 || d.M <= 0 || d.M > 1024 || d.D_out > 65535 || d.kernel_kind != DGP_KERNEL_RBF ||
+        d.mean_kind < 0 || d.mean_kind > 2)
+      return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: unsupported layer description (RBF kernel, M <= 1024)");
+    if (l > 0 && d.D_in != layers[l - 1].D_out) return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: layer dims do not chain");
+    if (d.mean_kind == DGP_MEAN_IDENTITY && d.D_in != d.D_out)
+      return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: identity mean needs D_in == D_out");
+    Layer y{};
+    y.d = d;
+    y.Mp = (int)round_up(d.M, 16);
+    y.off_Z = off; off += (long)d.M * d.D_in;
+    y.off_var = off; off += 1;
+    y.off_ls = off; off += d.D_in;
+    y.off_qmu = off; off += (long)d.M * d.D_out;
+    y.off_qsqrt = off; off += (long)d.D_out * d.M * d.M;
+    const long MM = (long)y.Mp * y.Mp;
+    y.acc_Q = aoff; aoff += MM;
+    y.acc_dW = aoff; aoff += MM * d.D_out;
+    y.acc_du = aoff; aoff += round_up((long)y.Mp * d.D_out, 2);
+    y.acc_dZ = aoff; aoff += round_up((long)d.M * d.D_in, 2);
+    y.acc_dls = aoff; aoff += round_up(d.D_in, 2);
+    y.acc_dvar = aoff; aoff += 2;
+    Mpmax = std::max(Mpmax, y.Mp);
+    Dmax = std::max(Dmax, d.D_out);
+    ctx->L.push_back(y);
+    if (d.mean_kind == DGP_MEAN_LINEAR) moff += (long)d.D_in * d.D_out + d.D_out;
+  }
+  off += 1;   // likelihood variance
+  if (off != n_params) { free_model(ctx); return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: n_params does not match the layer list"); }
+  if (moff != n_mean_params || (moff > 0 && !mean_params)) {
+    free_model(ctx);
+    return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: n_mean_params does not match the layer list");
+  }
+  ctx->n_params = off;
+  ctx->n_acc = aoff;
+  RET(dev_alloc(ctx, &ctx->params, off));
+  RET(dev_alloc(ctx, &ctx->grad, off));
+  RET(dev_alloc(ctx, &ctx->adam_m, off));
+  RET(dev_alloc(ctx, &ctx->adam_v, off));
+  RET(dev_alloc(ctx, &ctx->acc_own, aoff));
+  ctx->acc = ctx->acc_own;
+  HIPCHK(hipMemcpy(ctx->params, flat_params, off * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(ctx->adam_m, 0, off * 8));
+  HIPCHK(hipMemset(ctx->adam_v, 0, off * 8));
+  HIPCHK(hipMemset(ctx->grad, 0, off * 8));
+  ctx->adam_t = 0;
+  if (moff > 0) {
+    RET(dev_alloc(ctx, &ctx->mean_params, moff));
+    HIPCHK(hipMemcpy(ctx->mean_params, mean_params, moff * 8, hipMemcpyHostToDevice));
+  }
+  moff = 0;
+  ctx->segs.clear();
+  for (auto& y : ctx->L) {
+    const long MM = (long)y.Mp * y.Mp;
+    const int D = y.d.D_out;
+    RET(dev_alloc(ctx, &y.Kuu, MM)); RET(dev_alloc(ctx, &y.Lu, MM)); RET(dev_alloc(ctx, &y.Linv, MM));
+    RET(dev_alloc(ctx, &y.Lq, MM * D)); RET(dev_alloc(ctx, &y.qmu_p, (long)y.Mp * D));
+    RET(dev_alloc(ctx, &y.Wcat, MM * D)); RET(dev_alloc(ctx, &y.u, (long)y.Mp * D));
+    RET(dev_alloc(ctx, &y.dLq, MM * D)); RET(dev_alloc(ctx, &y.dqmu_p, (long)y.Mp * D));
+    if (y.d.mean_kind == DGP_MEAN_LINEAR) {
+      y.meanW = ctx->mean_params + moff; moff += (long)y.d.D_in * D;
+      y.meanb = ctx->mean_params + moff; moff += D;
+    }
+    ctx->segs.push_back({y.off_Z, (long)y.d.M * y.d.D_in, TR_IDENTITY, 1, 0});
+    ctx->segs.push_back({y.off_var, 1, TR_SOFTPLUS, 1, 0});
+    ctx->segs.push_back({y.off_ls, y.d.D_in, TR_SOFTPLUS, 1, 0});
+    ctx->segs.push_back({y.off_qmu, (long)y.d.M * D, TR_IDENTITY, 1, 0});
+    ctx->segs.push_back({y.off_qsqrt, (long)D * y.d.M * y.d.M, TR_TRIL, 1, y.d.M});
+  }
+  ctx->segs.push_back({off - 1, 1, TR_SOFTPLUS_SHIFT, 1, 0});
+  RET(dev_alloc(ctx, &ctx->segs_dev, ctx->segs.size()));
+  const size_t each = (size_t)Mpmax * Mpmax * Dmax;
+  for (auto& s : ctx->sm) RET(dev_alloc(ctx, &s, each));
+  return DGP_OK;
+}
+
+int64_t dgp_param_count(const dgp_ctx* ctx) { return ctx ? ctx->n_params : 0; }
+
+int dgp_params_get(dgp_ctx* ctx, double* flat_out) {
+  if (!ctx || !ctx->params || !flat_out) return fail(ctx, DGP_ERR_INVALID, "dgp_params_get: no model");
+  HIPCHK(hipMemcpyAsync(flat_out, ctx->params, ctx->n_params * 8, hipMemcpyDeviceToHost, ctx->st));
+  return check_flags(ctx);
+}
+
+int dgp_params_set(dgp_ctx* ctx, const double* flat_in) {
+  if (!ctx || !ctx->params || !flat_in) return fail(ctx, DGP_ERR_INVALID, "dgp_params_set: no model");
+  HIPCHK(hipMemcpyAsync(ctx->params, flat_in, ctx->n_params * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  ctx->grad_ready = false;
+  return DGP_OK;
+}
+
+int dgp_data_set(dgp_ctx* ctx, const double* X, const double* Y, int64_t N, int32_t D, int32_t Dy, int64_t n_global_offset) {
+  if (!ctx || !X || !Y || N <= 0 || D <= 0 || Dy <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_data_set: bad arguments");
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  dev_free(ctx->X); dev_free(ctx->Y);
+  RET(dev_alloc(ctx, &ctx->X, (size_t)N * D));
+  RET(dev_alloc(ctx, &ctx->Y, (size_t)N * Dy));
+  HIPCHK(hipMemcpy(ctx->X, X, (size_t)N * D * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->Y, Y, (size_t)N * Dy * 8, hipMemcpyHostToDevice));
+  ctx->N = N; ctx->D = D; ctx->Dy = Dy; ctx->n_goff = n_global_offset;
+  return DGP_OK;
+}
+
+int dgp_set_workspace_limit(dgp_ctx* ctx, int64_t bytes) {
+  if (!ctx || bytes < (1 << 20)) return fail(ctx, DGP_ERR_INVALID, "dgp_set_workspace_limit: at least 1 MiB");
+  ctx->ws_limit = bytes;
+  return DGP_OK;
+}
+
+static int check_ready(dgp_ctx* ctx, bool need_data) {
+  if (!ctx) return DGP_ERR_INVALID;
+  if (ctx->L.empty()) return fail(ctx, DGP_ERR_INVALID, "no model: call dgp_model_set first");
+  if (need_data) {
+    if (!ctx->X) return fail(ctx, DGP_ERR_INVALID, "no data: call dgp_data_set first");
+    if (ctx->D != ctx->L[0].d.D_in || ctx->Dy != ctx->L.back().d.D_out)
+      return fail(ctx, DGP_ERR_INVALID, "data dimensions do not match the model");
+  }
+  return DGP_OK;
+}
+
+int dgp_elbo(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs, double* data_term, double* kl) {
+  RET(check_ready(ctx, true));
+  if (S <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_elbo: S must be positive");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (zs) RET(upload_zs(ctx, zs, S, ctx->N));
+  RET(prep(ctx));
+  long Nc = 0;
+  RET(ensure_ws(ctx, ctx->N, S, false, &Nc));
+  Layer& last = ctx->L.back();
+  const bool dedup_last = ctx->L.size() == 1;
+  for (long n0 = 0; n0 < ctx->N; n0 += Nc) {
+    const long nc = std::min(Nc, ctx->N - n0);
+    RET(forward_chunk(ctx, ctx->X, ctx->N, n0, nc, S, seed, zs != nullptr, ctx->n_goff));
+    ProfScope ps(ctx, 1, 0, 0);
+    HIPCHK(gauss_lik(ctx->st, last.mean, last.var, ctx->Y, n0, nc, S, dedup_last ? 1 : 0, ctx->Dy,
+                     P(ctx, ctx->n_params - 1), ctx->scal + 2, nullptr, nullptr, nullptr, nullptr));
+  }
+  double h[4];
+  HIPCHK(hipMemcpyAsync(h, ctx->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->st));
+  RET(check_flags(ctx));
+  if (data_term) *data_term = h[2];
+  if (kl) *kl = h[0];
+  if (!std::isfinite(h[2]) || !std::isfinite(h[0])) return fail(ctx, DGP_ERR_NONFINITE, "ELBO is not finite");
+  return DGP_OK;
+}
+
+int dgp_propagate(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
+                  double* const* Fs, double* const* Fmeans, double* const* Fvars, int32_t add_lik_var) {
+  RET(check_ready(ctx, false));
+  if (!Xnew || Nn <= 0 || S <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_propagate: bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nl = (int)ctx->L.size();
+  const int Din0 = ctx->L[0].d.D_in;
+  RET(grow(ctx, &ctx->Xnew, &ctx->Xnew_cap, (size_t)Nn * Din0));
+  HIPCHK(hipMemcpyAsync(ctx->Xnew, Xnew, (size_t)Nn * Din0 * 8, hipMemcpyHostToDevice, ctx->st));
+  if (zs) RET(upload_zs(ctx, zs, S, Nn));
+  double* const* outs[3] = {Fs, Fmeans, Fvars};
+  for (int k = 0; k < 3; ++k) {
+    if ((int)ctx->out_dev[k].size() < nl) { ctx->out_dev[k].resize(nl, nullptr); ctx->out_cap[k].resize(nl, 0); }
+    for (int l = 0; l < nl; ++l)
+      if (outs[k] && outs[k][l]) RET(grow(ctx, &ctx->out_dev[k][l], &ctx->out_cap[k][l], (size_t)S * Nn * ctx->L[l].d.D_out));
+  }
+  RET(prep(ctx));
+  long Nc = 0;
+  RET(ensure_ws(ctx, Nn, S, false, &Nc));
+  for (long n0 = 0; n0 < Nn; n0 += Nc) {
+    const long nc = std::min(Nc, (long)Nn - n0);
+    RET(forward_chunk(ctx, ctx->Xnew, Nn, n0, nc, S, seed, zs != nullptr, 0));
+    for (int l = 0; l < nl; ++l) {
+      Layer& y = ctx->L[l];
+      const int D = y.d.D_out;
+      const int dd = (l == 0) ? 1 : 0;
+      ProfScope ps(ctx, 1, 0, 0);
+      if (l == nl - 1 && add_lik_var)
+        HIPCHK(lik_predict_var(ctx->st, y.var, (dd ? nc : (long)S * nc) * D, P(ctx, ctx->n_params - 1)));
+      if (Fs && Fs[l]) HIPCHK(expand_rows(ctx->st, y.F, nc, S, D, 0, ctx->out_dev[0][l], Nn, n0));
+      if (Fmeans && Fmeans[l]) HIPCHK(expand_rows(ctx->st, y.mean, nc, S, D, dd, ctx->out_dev[1][l], Nn, n0));
+      if (Fvars && Fvars[l]) HIPCHK(expand_rows(ctx->st, y.var, nc, S, D, dd, ctx->out_dev[2][l], Nn, n0));
+    }
+  }
+  for (int k = 0; k < 3; ++k)
+    for (int l = 0; l < nl; ++l)
+      if (outs[k] && outs[k][l])
+        HIPCHK(hipMemcpyAsync(outs[k][l], ctx->out_dev[k][l], (size_t)S * Nn * ctx->L[l].d.D_out * 8,
+                              hipMemcpyDeviceToHost, ctx->st));
+  return check_flags(ctx);
+}
+
+int dgp_grad_partial(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs) {
+  RET(check_ready(ctx, true));
+  if (S <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_grad_partial: S must be positive");
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->grad_ready = false;
+  if (zs) RET(upload_zs(ctx, zs, S, ctx->N));
+  RET(prep(ctx));
+  HIPCHK(hipMemsetAsync(ctx->acc, 0, ctx->n_acc * 8, ctx->st));
+  long Nc = 0;
+  RET(ensure_ws(ctx, ctx->N, S, true, &Nc));
+  Layer& last = ctx->L.back();
+  const bool dedup_last = ctx->L.size() == 1;
+  for (long n0 = 0; n0 < ctx->N; n0 += Nc) {
+    const long nc = std::min(Nc, ctx->N - n0);
+    RET(forward_chunk(ctx, ctx->X, ctx->N, n0, nc, S, seed, zs != nullptr, ctx->n_goff));
+    {
+      ProfScope ps(ctx, 1, 0, 0);
+      HIPCHK(gauss_lik(ctx->st, last.mean, last.var, ctx->Y, n0, nc, S, dedup_last ? 1 : 0, ctx->Dy,
+                       P(ctx, ctx->n_params - 1), ctx->acc + 0, ctx->acc + 1, last.mbar, last.vbar,
+                       ctx->acc + last.acc_dvar));
+    }
+    RET(backward_chunk(ctx, n0, nc, S, seed, zs != nullptr));
+  }
+  return DGP_OK;
+}
+
+int dgp_acc_info(dgp_ctx* ctx, void** device_ptr, int64_t* n_doubles) {
+  if (!ctx || ctx->L.empty()) return fail(ctx, DGP_ERR_INVALID, "dgp_acc_info: no model");
+  if (device_ptr) *device_ptr = ctx->acc;
+  if (n_doubles) *n_doubles = ctx->n_acc;
+  return DGP_OK;
+}
+
+int dgp_acc_bind(dgp_ctx* ctx, void* external_device_ptr) {
+  if (!ctx || ctx->L.empty()) return fail(ctx, DGP_ERR_INVALID, "dgp_acc_bind: no model");
+  ctx->acc = external_device_ptr ? reinterpret_cast<double*>(external_device_ptr) : ctx->acc_own;
+  return DGP_OK;
+}
+
+int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out) {
+  RET(check_ready(ctx, false));
+  HIPCHK(hipSetDevice(ctx->device));
+  double* acc = ctx->acc;
+  double* g = ctx->grad;
+  for (auto& y : ctx->L) {
+    const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
+    const long MM = (long)Mp * Mp, DM = (long)D * Mp;
+    double *T1 = ctx->sm[0], *T2 = ctx->sm[1], *T3 = ctx->sm[2], *T4 = ctx->sm[3], *Sm = ctx->sm[4];
+    double *dW = acc + y.acc_dW, *du = acc + y.acc_du, *Q = acc + y.acc_Q;
+    ProfScope ps(ctx, 2, 0, 0);
+    HIPCHK(wbar_total(ctx->st, dW, y.Wcat, du, y.u, M, Mp, D));
+    if (!y.d.white) {
+      RET(G(ctx, 2, GEMM_NT, Mp, Mp, DM, dW, DM, y.Wcat, DM, T1, Mp, 1.0, 0));
+      RET(G(ctx, 2, GEMM_NT, Mp, Mp, D, du, D, y.u, D, T1, Mp, 1.0, 1));
+      RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Linv, Mp, T1, Mp, T2, Mp, 1.0, 0));
+      RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Linv, Mp, dW, DM, y.dLq, Mp, 1.0, 0, D, 0, Mp, MM));
+      RET(G(ctx, 2, GEMM_TN, Mp, D, Mp, y.Linv, Mp, du, D, y.dqmu_p, D, 1.0, 0));
+      HIPCHK(lubar_finish(ctx->st, Q, T2, y.Lu, M, Mp, D, 0));
+    } else {
+      // W_d = L_q,d, u = q_mu: gradients pass straight through
+      for (int d = 0; d < D; ++d)
+        HIPCHK(hipMemcpy2DAsync(y.dLq + (long)d * MM, Mp * 8, dW + (long)d * Mp, DM * 8, Mp * 8, Mp,
+                                hipMemcpyDeviceToDevice, ctx->st));
+      HIPCHK(copy_mat(ctx->st, du, y.dqmu_p, (long)Mp * D));
+      HIPCHK(lubar_finish(ctx->st, Q, nullptr, y.Lu, M, Mp, D, 1));
+    }
+    HIPCHK(lqbar_finish(ctx->st, y.dLq, y.Lq, M, Mp, D));
+    // Cholesky backward: dKuu = sym(Lu^-T Phi(Lu^T dLu) Lu^-1)      
+    RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Lu, Mp, Q, Mp, T3, Mp, 1.0, 0));
+    HIPCHK(phi_tril_halfdiag(ctx->st, T3, Mp, 1));
+    RET(G(ctx, 2, GEMM_NN, Mp, Mp, Mp, T3, Mp, y.Linv, Mp, T4, Mp, 1.0, 0));
+    RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Linv, Mp, T4, Mp, Sm, Mp, 1.0, 0));
+    HIPCHK(rbf_kuu_bwd(ctx->st, Sm, y.Kuu, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
+                       acc + y.acc_dZ, acc + y.acc_dls, acc + y.acc_dvar));
+    HIPCHK(copy_mat(ctx->st, acc + y.acc_dZ, g + y.off_Z, (long)M * Din));
+    HIPCHK(copy_mat(ctx->st, acc + y.acc_dvar, g + y.off_var, 1));
+    HIPCHK(copy_mat(ctx->st, acc + y.acc_dls, g + y.off_ls, Din));
+    HIPCHK(unpack_q_grads(ctx->st, y.dLq, y.dqmu_p, M, Mp, D, g + y.off_qsqrt, g + y.off_qmu));
+  }
+  HIPCHK(copy_mat(ctx->st, acc + 1, g + ctx->n_params - 1, 1));
+  HIPCHK(sub_scalars(ctx->st, acc + 0, ctx->scal + 0, ctx->scal + 1));   // ELBO = data term - sum KL
+  ctx->grad_ready = true;
+  if (elbo_out) return dgp_last_elbo(ctx, elbo_out);
+  return DGP_OK;
+}
+
+int dgp_last_elbo(dgp_ctx* ctx, double* elbo_out) {
+  if (!ctx || !elbo_out) return DGP_ERR_INVALID;
+  double h[4];
+  HIPCHK(hipMemcpyAsync(h, ctx->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->st));
+  RET(check_flags(ctx));
+  *elbo_out = h[1];
+  return DGP_OK;
+}
+
+int dgp_grad_get(dgp_ctx* ctx, double* flat_grad_out) {
+  if (!ctx || !flat_grad_out || !ctx->grad_ready) return fail(ctx, DGP_ERR_INVALID, "dgp_grad_get: no gradient (call dgp_grad_finish)");
+  HIPCHK(hipMemcpyAsync(flat_grad_out, ctx->grad, ctx->n_params * 8, hipMemcpyDeviceToHost, ctx->st));
+  return check_flags(ctx);
+}
+
+int dgp_adam_reset(dgp_ctx* ctx) {
+  if (!ctx || !ctx->params) return fail(ctx, DGP_ERR_INVALID, "dgp_adam_reset: no model");
+  HIPCHK(hipMemsetAsync(ctx->adam_m, 0, ctx->n_params * 8, ctx->st));
+  HIPCHK(hipMemsetAsync(ctx->adam_v, 0, ctx->n_params * 8, ctx->st));
+  ctx->adam_t = 0;
+  return DGP_OK;
+}
+
+int dgp_adam_step(dgp_ctx* ctx, double lr, double beta_1, double beta_2, double epsilon, const uint8_t* trainable) {
+  if (!ctx || !ctx->grad_ready) return fail(ctx, DGP_ERR_INVALID, "dgp_adam_step: no gradient (call dgp_grad_finish)");
+  bool changed = !ctx->segs_uploaded;
+  for (size_t i = 0; i < ctx->segs.size(); ++i) {
+    const int t = trainable ? (trainable[i] ? 1 : 0) : 1;
+    if (ctx->segs[i].trainable != t) { ctx->segs[i].trainable = t; changed = true; }
+  }
+  if (changed) {   // rare: only when gpflow.set_trainable-style flags change
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipMemcpy(ctx->segs_dev, ctx->segs.data(), ctx->segs.size() * sizeof(ParamSeg), hipMemcpyHostToDevice));
+    ctx->segs_uploaded = true;
+  }
+  ctx->adam_t += 1;
+  const double t = (double)ctx->adam_t;
+  const double lr_t = lr * std::sqrt(1.0 - std::pow(beta_2, t)) / (1.0 - std::pow(beta_1, t));
+  ProfScope ps(ctx, 3, 0, (double)ctx->n_params * 48);
+  HIPCHK(adam_apply(ctx->st, ctx->params, ctx->grad, ctx->adam_m, ctx->adam_v, ctx->segs_dev, (int)ctx->segs.size(),
+                    ctx->n_params, lr_t, beta_1, beta_2, epsilon));
+  return DGP_OK;
+}
+
+int dgp_natgrad_step(dgp_ctx* ctx, double gamma, const uint8_t* layer_mask) {
+  if (!ctx || !ctx->grad_ready) return fail(ctx, DGP_ERR_INVALID, "dgp_natgrad_step: no gradient (call dgp_grad_finish)");
+  for (size_t l = 0; l < ctx->L.size(); ++l) {
+    if (layer_mask && !layer_mask[l]) continue;
+    Layer& y = ctx->L[l];
+    const int M = y.d.M, Mp = y.Mp, D = y.d.D_out;
+    const long MM = (long)Mp * Mp;
+    double *Li = ctx->sm[0], *T = ctx->sm[1], *T1 = ctx->sm[2], *Gm = ctx->sm[3], *Pinv = ctx->sm[4], *Pn = ctx->sm[5],
+           *Ri = ctx->sm[6], *Sn = ctx->sm[7];
+    ProfScope ps(ctx, 2, 0, 0);
+    HIPCHK(trinv_lower(ctx->st, y.Lq, Li, Mp, D));
+    RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Lq, Mp, y.dLq, Mp, T, Mp, 1.0, 0, D, MM, MM, MM));
+    HIPCHK(phi_tril_halfdiag(ctx->st, T, Mp, D));
+    RET(G(ctx, 2, GEMM_NN, Mp, Mp, Mp, T, Mp, Li, Mp, T1, Mp, 1.0, 0, D, MM, MM, MM));
+    RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, Li, Mp, T1, Mp, Gm, Mp, 1.0, 0, D, MM, MM, MM));       // d ELBO / d Sigma (unsym.)
+    RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, Li, Mp, Li, Mp, Pinv, Mp, 1.0, 0, D, MM, MM, MM));     // Sigma^-1
+    HIPCHK(symmetrize_axpy(ctx->st, Gm, Pinv, -2.0 * gamma, Pn, Mp, D));                       // loss = -ELBO
+    HIPCHK(chol_lower(ctx->st, Pn, Mp, D, ctx->info));
+    HIPCHK(trinv_lower(ctx->st, Pn, Ri, Mp, D));
+    RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, Ri, Mp, Ri, Mp, Sn, Mp, 1.0, 0, D, MM, MM, MM));       // Sigma'
+    HIPCHK(natgrad_mu(ctx->st, Sn, y.dqmu_p, gamma, y.qmu_p, M, Mp, D));
+    HIPCHK(copy_mat(ctx->st, Sn, y.Lq, MM * D));
+    HIPCHK(chol_lower(ctx->st, y.Lq, Mp, D, ctx->info));
+    HIPCHK(store_q(ctx->st, y.Lq, y.qmu_p, M, Mp, D, ctx->params + y.off_qsqrt, ctx->params + y.off_qmu));
+  }
+  return DGP_OK;
+}
+
+int dgp_prof_enable(dgp_ctx* ctx, int32_t on) {
+  if (!ctx) return DGP_ERR_INVALID;
+  RET(prof_drain(ctx));
+  Prof& p = ctx->prof;
+  p.on = on != 0;
+  for (int c = 0; c < kNCat; ++c) { p.ms[c] = p.flops[c] = p.bytes[c] = 0; p.launches[c] = 0; }
+  return DGP_OK;
+}
+
+int dgp_prof_read(dgp_ctx* ctx, int32_t n_cat, double* ms_out, int64_t* launches_out, double* alg_flops_out,
+                  double* alg_bytes_out) {
+  if (!ctx) return DGP_ERR_INVALID;
+  RET(prof_drain(ctx));
+  Prof& p = ctx->prof;
+  for (int c = 0; c < n_cat && c < kNCat; ++c) {
+    if (ms_out) ms_out[c] = p.ms[c];
+    if (launches_out) launches_out[c] = p.launches[c];
+    if (alg_flops_out) alg_flops_out[c] = p.flops[c];
+    if (alg_bytes_out) alg_bytes_out[c] = p.bytes[c];
+    p.ms[c] = p.flops[c] = p.bytes[c] = 0;
+    p.launches[c] = 0;
+  }
+  return DGP_OK;
+}
+
+// ----------------------------------------------------------------------------------- unit-level hooks
+int dgp_dev_gemm(dgp_ctx* ctx, int32_t op, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B,
+                 int64_t ldb, double* C, int64_t ldc, double alpha, int32_t beta, int32_t splits, int32_t tri,
+                 int64_t triblk, int32_t repeats, double* ms_per_call) {
+  if (!ctx || !A || !B || !C || op < 0 || op > 2) return fail(ctx, DGP_ERR_INVALID, "dgp_dev_gemm: bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  const long ar = (op == GEMM_TN) ? K : M, br = (op == GEMM_NT) ? N : K;
+  double *dA, *dB, *dC;
+  RET(dev_alloc(ctx, &dA, (size_t)ar * lda));
+  RET(dev_alloc(ctx, &dB, (size_t)br * ldb));
+  RET(dev_alloc(ctx, &dC, (size_t)M * ldc));
+  HIPCHK(hipMemcpy(dA, A, (size_t)ar * lda * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dB, B, (size_t)br * ldb * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dC, C, (size_t)M * ldc * 8, hipMemcpyHostToDevice));
+  int rc = G(ctx, 0, (GemmOp)op, M, N, K, dA, lda, dB, ldb, dC, ldc, alpha, beta, 1, 0, 0, 0, splits, tri, triblk);
+  if (rc == DGP_OK) {
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipMemcpy(C, dC, (size_t)M * ldc * 8, hipMemcpyDeviceToHost));
+    if (repeats > 0 && ms_per_call) {
+      hipEvent_t e0, e1;
+      HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+      HIPCHK(hipEventRecord(e0, ctx->st));
+      for (int r = 0; r < repeats && rc == DGP_OK; ++r)
+        rc = G(ctx, 0, (GemmOp)op, M, N, K, dA, lda, dB, ldb, dC, ldc, alpha, beta, 1, 0, 0, 0, splits, tri, triblk);
+      HIPCHK(hipEventRecord(e1, ctx->st));
+      HIPCHK(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+      *ms_per_call = ms / repeats;
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+  }
+  dev_free(dA); dev_free(dB); dev_free(dC);
+  return rc;
+}
+
+int dgp_dev_chol(dgp_ctx* ctx, double* A, int32_t M, int32_t batch) {
+  if (!ctx || !A || M <= 0 || M % 16 != 0 || batch <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_dev_chol: M must be a multiple of 16");
+  double* d;
+  const size_t n = (size_t)batch * M * M;
+  RET(dev_alloc(ctx, &d, n));
+  HIPCHK(hipMemcpy(d, A, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(chol_lower(ctx->st, d, M, batch, ctx->info));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  HIPCHK(hipMemcpy(A, d, n * 8, hipMemcpyDeviceToHost));
+  dev_free(d);
+  return check_flags(ctx);
+}
+
+int dgp_dev_trinv(dgp_ctx* ctx, const double* L, double* X, int32_t M, int32_t batch) {
+  if (!ctx || !L || !X || M <= 0 || batch <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_dev_trinv: bad arguments");
+  double *dl, *dx;
+  const size_t n = (size_t)batch * M * M;
+  RET(dev_alloc(ctx, &dl, n)); RET(dev_alloc(ctx, &dx, n));
+  HIPCHK(hipMemcpy(dl, L, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(trinv_lower(ctx->st, dl, dx, M, batch));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  HIPCHK(hipMemcpy(X, dx, n * 8, hipMemcpyDeviceToHost));
+  dev_free(dl); dev_free(dx);
+  return DGP_OK;
+}
+
+}  // extern "C"
+
+
+extern "C" {
+
+int dgp_dev_normals(dgp_ctx* ctx, uint64_t seed, int32_t layer, int32_t S, int64_t n0, int64_t N, int32_t D, double* z_out) {
+  if (!ctx || !z_out || S <= 0 || N <= 0 || D <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_dev_normals: bad arguments");
+  double* d;
+  const size_t n = (size_t)S * N * D;
+  RET(dev_alloc(ctx, &d, n));
+  ZSource z;
+  z.zs = nullptr; z.seed = seed; z.layer = layer; z.n_global0 = n0; z.Ntot = N;
+  HIPCHK(launch_normals(ctx->st, z, S, (long)N, D, d));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  HIPCHK(hipMemcpy(z_out, d, n * 8, hipMemcpyDeviceToHost));
+  dev_free(d);
+  return DGP_OK;
+}
+
+int dgp_dev_mfma_peak(dgp_ctx* ctx, int32_t iters, double* tflops_out) {
+  if (!ctx || iters <= 0 || !tflops_out) return fail(ctx, DGP_ERR_INVALID, "dgp_dev_mfma_peak: bad arguments");
+  int cus = 256;
+  hipDeviceProp_t p;
+  HIPCHK(hipGetDeviceProperties(&p, ctx->device));
+  cus = p.multiProcessorCount;
+  double* sink;
+  const int blocks = cus * 4;
+  RET(dev_alloc(ctx, &sink, (size_t)blocks * 256));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(launch_mfma_peak(ctx->st, blocks, iters, sink));   // warm-up
+  HIPCHK(hipEventRecord(e0, ctx->st));
+  HIPCHK(launch_mfma_peak(ctx->st, blocks, iters, sink));
+  HIPCHK(hipEventRecord(e1, ctx->st));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  // per wave: iters * 8 MFMAs of 16x16x4 (2*16*16*4 flops each); 4 waves per block
+  const double flops = (double)blocks * 4.0 * iters * 8.0 * 2048.0;
+  *tflops_out = flops / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  dev_free(sink);
+  return DGP_OK;
+}
+
+}  // extern "C"

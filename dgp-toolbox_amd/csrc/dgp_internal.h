@@ -1,0 +1,92 @@
+// Internal declarations shared by the HIP translation units of libdgp_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_f64.h"
+
+namespace dgp {
+
+constexpr double kJitter = 1e-6;        // gpflow.default_jitter()  (layers.py:222,230; utils.py:41)
+constexpr double kLikVarLower = 1e-6;   // gpflow Gaussian variance lower bound ("Softplus + Shift")
+
+// ---------------------------------------------------------------- small matrices (smallmat.hip)
+// All matrices are row-major [Mp x Mp] with leading dimension Mp, batched with stride Mp*Mp.
+hipError_t rbf_kuu(hipStream_t st, const double* Z, const double* var, const double* ls, int M, int Mp, int Din,
+                   double* Kuu /* + jitter*I, identity on the padding */);
+hipError_t chol_lower(hipStream_t st, double* A, int Mp, int batch, int* info /* device flag, set on non-PD */);
+hipError_t trinv_lower(hipStream_t st, const double* L, double* X, int Mp, int batch);
+// Lq[d] (padded, identity padding) <- tril(q_sqrt[d]) ; qmu_p (padded rows zero) <- q_mu
+hipError_t pack_q(hipStream_t st, const double* q_sqrt, const double* q_mu, int M, int Mp, int D, double* Lq,
+                  double* qmu_p);
+// Wcat[k][d*Mp+n] <- Lq[d][k][n]   (white case: W_d = q_sqrt_d)
+hipError_t lq_to_wcat(hipStream_t st, const double* Lq, int Mp, int D, double* Wcat);
+hipError_t copy_mat(hipStream_t st, const double* src, double* dst, long n);
+// KL of one layer (layers.py:280-308) from W, u, diag(Lq), diag(Lu); adds into *kl_out (device)
+hipError_t layer_kl(hipStream_t st, const double* Wcat, const double* u, const double* Lq, const double* Lu, int M,
+                    int Mp, int D, int white, double* kl_out);
+// elementwise pieces of the backward chain
+hipError_t wbar_total(hipStream_t st, double* dWcat, const double* Wcat, double* du, const double* u, int M, int Mp,
+                      int D);                                               // dW <- tril(dW) - W ; du <- du - u
+hipError_t lqbar_finish(hipStream_t st, double* dLq, const double* Lq, int M, int Mp, int D);   // tril + 1/diag
+hipError_t lubar_finish(hipStream_t st, double* dLu /* in: Q (+T2) */, const double* T2_or_null, const double* Lu,
+                        int M, int Mp, int D, int white);                   // -tril(Q+T2) - D diag(1/Lu)
+hipError_t phi_tril_halfdiag(hipStream_t st, double* T, int Mp, int batch);
+hipError_t rbf_kuu_bwd(hipStream_t st, const double* S /* unsymmetrised dKuu */, const double* Kuu, const double* Z,
+                       const double* var, const double* ls, int M, int Mp, int Din, double* dZ, double* dls,
+                       double* dvar);
+hipError_t unpack_q_grads(hipStream_t st, const double* dLq, const double* dqmu_p, int M, int Mp, int D,
+                          double* g_q_sqrt, double* g_q_mu);
+hipError_t symmetrize_axpy(hipStream_t st, const double* Gm, const double* Pinv, double two_gamma, double* out,
+                           int Mp, int batch);                              // out = Pinv + two_gamma * 0.5 (G + G^T)
+hipError_t natgrad_mu(hipStream_t st, const double* Sn, const double* g_qmu_p, double gamma, double* qmu_p, int M,
+                      int Mp, int D);                                       // mu_d -= gamma * Sn_d g_d
+hipError_t sub_scalars(hipStream_t st, const double* a, const double* b, double* out);   // out = a - b
+hipError_t store_q(hipStream_t st, const double* Lq, const double* qmu_p, int M, int Mp, int D, double* q_sqrt,
+                   double* q_mu);
+
+// ---------------------------------------------------------------- per-point kernels (points.hip)
+struct ZSource {           // where the N(0,1) draws of one layer come from
+  const double* zs;        // injected [S, Ntot, D] (device) or nullptr -> Philox
+  uint64_t seed;
+  int layer;
+  long n_global0;          // global index of local point 0 of the data set (Philox counter)
+  long Ntot;               // row count of the injected array
+};
+
+hipError_t rbf_kuf(hipStream_t st, const double* Xin, long P, long x_row0, const double* Z, const double* var,
+                   const double* ls, int M, int Mp, int Din, double* Kt);
+// var/mean/sample stage of a layer (layers.py:249-278 + utils.py:41). `dedup`: the P rows are the Nc data
+// points of the first layer (identical for every sample s); F is always written for all S*Nc rows.
+hipError_t var_mean_sample(hipStream_t st, const double* Ct, const double* Tt, const double* u, const double* Xin,
+                           long x_row0, long P, long Nc, int S, int dedup, int M, int Mp, int Din, int D,
+                           const double* kvar, int mean_kind, const double* meanW, const double* meanb, ZSource zsrc,
+                           long n_chunk0, double* mean, double* var, double* F);
+// Gaussian variational expectations (gpflow Gaussian, via utils.py:89-93) + seeds of the backward pass
+hipError_t gauss_lik(hipStream_t st, const double* mean, const double* var, const double* Y, long y_row0, long Nc,
+                     int S, int dedup, int Dy, const double* lik_var, double* acc_elbo, double* acc_dlik,
+                     double* mbar, double* vbar, double* acc_dkvar);
+// fold dF into (mbar, vbar) of the producing layer; sums over s when dedup
+hipError_t fold_sample_grad(hipStream_t st, const double* Fbar, const double* var, long Nc, int S, int dedup, int D,
+                            ZSource zsrc, long n_chunk0, double* mbar, double* vbar, double* acc_dkvar);
+hipError_t scale_T(hipStream_t st, double* Tt, const double* vbar, long P, int Mp, int D);
+hipError_t cbar_fix(hipStream_t st, double* Cbar, const double* Ct, const double* mbar, const double* vbar,
+                    const double* u, long P, int Mp, int D);
+hipError_t rbf_kuf_bwd(hipStream_t st, const double* Kbar, const double* Kt, const double* Xin, long x_row0, long P,
+                       const double* Z, const double* var, const double* ls, int M, int Mp, int Din, int D,
+                       int mean_kind, const double* meanW, const double* mbar, int want_xbar, double* xbar,
+                       double* acc_dZ, double* acc_dls, double* acc_dvar);
+hipError_t expand_rows(hipStream_t st, const double* src, long Nc, int S, int D, int dedup, double* dst, long Ntot,
+                       long n0);
+hipError_t lik_predict_var(hipStream_t st, double* var, long n, const double* lik_var);
+hipError_t launch_normals(hipStream_t st, ZSource z, int S, long N, int D, double* out);
+hipError_t launch_mfma_peak(hipStream_t st, int blocks, int iters, double* sink);
+
+// ---------------------------------------------------------------- optimiser kernels (optim.hip)
+enum Transform : int { TR_IDENTITY = 0, TR_SOFTPLUS = 1, TR_SOFTPLUS_SHIFT = 2, TR_TRIL = 3 };
+struct ParamSeg { long off, n; int transform; int trainable; int rows; };   // rows: M for TR_TRIL blocks
+hipError_t adam_apply(hipStream_t st, double* params, const double* grad_elbo, double* m, double* v,
+                      const ParamSeg* segs_dev, int nseg, long total, double lr_t, double beta1, double beta2,
+                      double eps);
+
+}  // namespace dgp

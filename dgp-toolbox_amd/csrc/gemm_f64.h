@@ -1,0 +1,251 @@
+// fp64 MFMA GEMM engine for gfx950 (v_mfma_f64_16x16x4_f64), LDS-staged, 4 waves / workgroup.
+//
+// Every dense contraction of the SVGP-layer path runs through this one kernel family:
+//   forward   Ct  = Kt  * Linv^T        (reference: tf.linalg.triangular_solve, layers.py:245-247)
+//             Tt  = Ct  * Wcat          (reference: tf.matmul(SK, A_tiled),      layers.py:263)
+//   backward  dCt = sTt * Wcat^T,  dKt = dCt * Linv, and the reductions over points
+//             dWcat = Ct^T * sTt,  Q = dKt^T * Ct,  du = Ct^T * dm    (reference: tf.GradientTape)
+//   plus the M x M x M products of the small-matrix chain (Cholesky backward, natural gradient).
+//
+// Layout rules (all row-major, leading dimension in elements):
+//   C[M x N] (+)= alpha * op(A)[M x K] * op(B)[K x N]
+//   TA = false: A stored [M][K] (k contiguous);  TA = true: A stored [K][M] (m contiguous)
+//   TB = false: B stored [K][N] (n contiguous);  TB = true: B stored [N][K] (k contiguous)
+// LDS images keep the global orientation of each tile (so global loads and LDS stores are both
+// contiguous) and are padded so that the MFMA fragment reads (ds_read_b64, one f64 per lane) are
+// bank-conflict free: a k-contiguous image uses a row pitch of BK+2 doubles, an m/n-contiguous
+// image a pitch of BM+16 / BN+16 doubles (MI355X_MICROARCH.md §LDS: ds_read_b64 is serviced in two
+// 32-lane groups over 64 four-byte banks).
+//
+// MFMA operand maps for v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md §3): lane l holds
+// A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; the 4 results per lane are
+// D[row = (l>>4) + 4*r][col = l&15], r = 0..3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dgp {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+enum TriMode : int {
+  TRI_NONE = 0,
+  TRI_B_UPPER = 1,    // op(B)[k][n] == 0 unless (k mod triblk) <= (n mod triblk)
+  TRI_B_LOWER = 2,    // op(B)[k][n] == 0 unless (k mod triblk) >= (n mod triblk)
+  TRI_OUT_LOWER = 3,  // only C[m][n] with m >= (n mod triblk) is needed (tiles above are skipped)
+};
+
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  long lda, ldb, ldc;
+  long M, N, K;
+  long sA, sB, sC;   // batch strides (elements)
+  int batch;
+  int splits;        // split-K factor (>1 => atomic accumulation into C, C must be pre-initialised)
+  long ksplit;       // K range per split (multiple of BK)
+  double alpha;
+  int beta;          // 0: overwrite, 1: accumulate (non-atomic; ignored when splits > 1)
+  int tri;
+  long triblk;
+};
+
+template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int VB>
+struct GemmCfg {
+  static constexpr int WM = BM / WR, WN = BN / WC;
+  static constexpr int FM = WM / 16, FN = WN / 16;
+  static constexpr int LDA_S = TA ? (BM + 16) : (BK + 2);
+  static constexpr int LDB_S = TB ? (BK + 2) : (BN + 16);
+  static constexpr int A_ROWS = TA ? BK : BM, A_COLS = TA ? BM : BK;
+  static constexpr int B_ROWS = TB ? BN : BK, B_COLS = TB ? BK : BN;
+  static constexpr int AS_SZ = A_ROWS * LDA_S, BS_SZ = B_ROWS * LDB_S;
+  static constexpr int A_TPR = A_COLS / VA, B_TPR = B_COLS / VB;          // threads per tile row
+  static constexpr int A_RPP = 256 / A_TPR, B_RPP = 256 / B_TPR;          // rows per pass
+  static constexpr int A_PASS = (A_ROWS + A_RPP - 1) / A_RPP, B_PASS = (B_ROWS + B_RPP - 1) / B_RPP;
+  static_assert(WR * WC == 4, "4 waves per workgroup");
+  static_assert(WM % 16 == 0 && WN % 16 == 0 && BK % 4 == 0, "MFMA tile granularity");
+  static_assert(256 % A_TPR == 0 && 256 % B_TPR == 0, "loader shape");
+};
+
+// global -> registers for one operand tile (rows x contiguous cols), zero-filled outside [rmax, cmax)
+template <int ROWS, int COLS, int V, int TPR, int RPP, int PASS>
+__device__ __forceinline__ void tile_load(double (&reg)[PASS][V], const double* __restrict__ base, long ld,
+                                          long r0, long c0, long rmax, long cmax, int tid) {
+  const int tr = tid / TPR, tc = (tid % TPR) * V;
+#pragma unroll
+  for (int p = 0; p < PASS; ++p) {
+    const int r = p * RPP + tr;
+    const long gr = r0 + r, gc = c0 + tc;
+    const bool ok = (r < ROWS) && (gr < rmax) && (gc < cmax);
+    if constexpr (V == 2) {
+      d2_t v = {0.0, 0.0};
+      if (ok) v = *reinterpret_cast<const d2_t*>(base + gr * ld + gc);
+      reg[p][0] = v[0];
+      reg[p][1] = v[1];
+    } else {
+      reg[p][0] = ok ? base[gr * ld + gc] : 0.0;
+    }
+  }
+}
+
+template <int ROWS, int COLS, int V, int TPR, int RPP, int PASS, int LDS_LD>
+__device__ __forceinline__ void tile_store(const double (&reg)[PASS][V], double* __restrict__ s, int tid) {
+  const int tr = tid / TPR, tc = (tid % TPR) * V;
+#pragma unroll
+  for (int p = 0; p < PASS; ++p) {
+    const int r = p * RPP + tr;
+    if (r < ROWS) {
+      if constexpr (V == 2) {
+        d2_t v = {reg[p][0], reg[p][1]};
+        *reinterpret_cast<d2_t*>(s + r * LDS_LD + tc) = v;
+      } else {
+        s[r * LDS_LD + tc] = reg[p][0];
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int VB>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
+  using Cfg = GemmCfg<TA, TB, BM, BN, BK, WR, WC, VA, VB>;
+  constexpr int FM = Cfg::FM, FN = Cfg::FN;
+  __shared__ __attribute__((aligned(16))) double smem[2 * (Cfg::AS_SZ + Cfg::BS_SZ)];
+
+  // ---- tile coordinates: XCD-aware remap so that one XCD's L2 sees a contiguous run of tiles ----
+  const long tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  const long ntile = tiles_n * tiles_m;
+  long bid = blockIdx.x;
+  {
+    const long q = ntile / 8, r = ntile % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any ntile
+  }
+  const long tm = bid / tiles_n, tn = bid % tiles_n;     // column tiles fastest: neighbours share A rows
+  const long m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y;
+  const int bz = z / g.splits, sp = z % g.splits;
+
+  const long nloc0 = (g.tri != TRI_NONE && g.triblk > 0) ? (n0 % g.triblk) : n0;
+  const bool tri_ok = (g.tri != TRI_NONE) && (g.triblk % BN == 0 || g.N <= g.triblk);
+  if (g.tri == TRI_OUT_LOWER && tri_ok && (m0 + BM - 1) < nloc0) return;     // tile strictly above the diagonal
+
+  const double* __restrict__ A = g.A + (long)bz * g.sA;
+  const double* __restrict__ B = g.B + (long)bz * g.sB;
+  double* __restrict__ C = g.C + (long)bz * g.sC;
+
+  // ---- K ranges: `nkb` blocks of length kblen, inside each block k in [klo, khi) ----
+  long kblen = g.K, nkb = 1, klo = 0, khi = g.K;
+  if ((g.tri == TRI_B_UPPER || g.tri == TRI_B_LOWER) && tri_ok) {
+    kblen = (g.K > g.triblk) ? g.triblk : g.K;
+    nkb = g.K / kblen;
+    if (g.tri == TRI_B_UPPER) { khi = nloc0 + BN; if (khi > kblen) khi = kblen; }
+    else { klo = (nloc0 / BK) * BK; khi = kblen; }
+  } else if (g.splits > 1) {
+    klo = (long)sp * g.ksplit;
+    khi = klo + g.ksplit; if (khi > g.K) khi = g.K;
+    if (klo >= khi) return;
+  }
+  const long ktiles_per_blk = (khi - klo + BK - 1) / BK;
+  const long ktiles = ktiles_per_blk * nkb;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int li = lane & 15, lk = lane >> 4;
+
+  d4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+  double ra[Cfg::A_PASS][VA], rb[Cfg::B_PASS][VB];
+
+  auto kabs_of = [&](long kt) -> long {
+    const long kb = kt / ktiles_per_blk, kk = kt % ktiles_per_blk;
+    return kb * kblen + klo + kk * BK;
+  };
+  auto kend_of = [&](long kt) -> long {
+    const long kb = kt / ktiles_per_blk;
+    return kb * kblen + khi;
+  };
+  auto gload = [&](long kt) {
+    const long k0 = kabs_of(kt), kend = kend_of(kt);
+    if constexpr (TA)
+      tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, k0, m0, kend, g.M, tid);
+    else
+      tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, m0, k0, g.M, kend, tid);
+    if constexpr (TB)
+      tile_load<Cfg::B_ROWS, Cfg::B_COLS, VB, Cfg::B_TPR, Cfg::B_RPP, Cfg::B_PASS>(rb, B, g.ldb, n0, k0, g.N, kend, tid);
+    else
+      tile_load<Cfg::B_ROWS, Cfg::B_COLS, VB, Cfg::B_TPR, Cfg::B_RPP, Cfg::B_PASS>(rb, B, g.ldb, k0, n0, kend, g.N, tid);
+  };
+  auto sstore = [&](int buf) {
+    double* as = smem + buf * (Cfg::AS_SZ + Cfg::BS_SZ);
+    double* bs = as + Cfg::AS_SZ;
+    tile_store<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS, Cfg::LDA_S>(ra, as, tid);
+    tile_store<Cfg::B_ROWS, Cfg::B_COLS, VB, Cfg::B_TPR, Cfg::B_RPP, Cfg::B_PASS, Cfg::LDB_S>(rb, bs, tid);
+  };
+
+  if (ktiles > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+
+  for (long kt = 0; kt < ktiles; ++kt) {
+    const int cur = (int)(kt & 1);
+    const bool more = (kt + 1 < ktiles);
+    if (more) gload(kt + 1);                       // next tile's global loads fly under the MFMAs
+    const double* as = smem + cur * (Cfg::AS_SZ + Cfg::BS_SZ);
+    const double* bs = as + Cfg::AS_SZ;
+#pragma unroll
+    for (int k4 = 0; k4 < BK / 4; ++k4) {
+      double fa[FM], fb[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wr * Cfg::WM + i * 16 + li, kk = k4 * 4 + lk;
+        fa[i] = TA ? as[kk * Cfg::LDA_S + row] : as[row * Cfg::LDA_S + kk];
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = wc * Cfg::WN + j * 16 + li, kk = k4 * 4 + lk;
+        fb[j] = TB ? bs[col * Cfg::LDB_S + kk] : bs[kk * Cfg::LDB_S + col];
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const bool atomic = g.splits > 1;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const long col = n0 + wc * Cfg::WN + j * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wr * Cfg::WM + i * 16 + lk + 4 * r;
+        if (row < g.M && col < g.N) {
+          double* p = C + row * g.ldc + col;
+          const double v = g.alpha * acc[i][j][r];
+          if (atomic) unsafeAtomicAdd(p, v);
+          else if (g.beta) *p += v;
+          else *p = v;
+        }
+      }
+    }
+  }
+}
+
+// Host-side dispatcher (defined in gemm_f64.hip)
+enum GemmOp : int { GEMM_NN = 0, GEMM_NT = 1, GEMM_TN = 2 };
+hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args);
+
+}  // namespace dgp

@@ -1,0 +1,467 @@
+// Per-point kernels of the SVGP-layer path (HBM-streaming stages around the MFMA contractions):
+// RBF Kuf assembly, the variance/mean/sample stage, Gaussian variational expectations, and their
+// hand-derived backward counterparts.  Point-major layouts: a point's M-vector
+// is contiguous, so every kernel here reads and writes fully coalesced rows.
+//
+// Reference lines:  Kuf = covs.Kuf(Z, kern, X) layers.py:243;  mean/var layers.py:249-278;
+// reparameterize utils.py:40-41;  Gaussian variational_expectations via utils.py:89-93 [ext];
+// the backward is what tf.GradientTape derives in dgp.py:272-275.
+#include "dgp_internal.h"
+
+namespace dgp {
+
+#define LAUNCH_CHECK() return hipGetLastError()
+
+// ---------------------------------------------------------------------------------------- Philox4x32-10
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+  const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+  const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+  c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+}
+
+// N(0,1) keyed by (seed, global point n, sample s, layer, output d): identical for any sharding.
+__device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t n, uint32_t s, uint32_t layer, uint32_t d) {
+  uint32_t c[4] = {(uint32_t)n, (uint32_t)(n >> 32), s, (layer << 16) | d};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const double two53 = 9007199254740992.0;
+  const double u1 = ((double)(((uint64_t)(c[0] >> 5) << 26) + (uint64_t)(c[1] >> 6)) + 0.5) / two53;
+  const double u2 = ((double)(((uint64_t)(c[2] >> 5) << 26) + (uint64_t)(c[3] >> 6)) + 0.5) / two53;
+  return sqrt(-2.0 * log(u1)) * cos(2.0 * 3.14159265358979323846 * u2);
+}
+
+__device__ __forceinline__ double draw_z(const ZSource& zs, int s, long n_local, int d, int D) {
+  if (zs.zs) return zs.zs[((long)s * zs.Ntot + n_local) * D + d];
+  return philox_normal(zs.seed, (uint64_t)(zs.n_global0 + n_local), (uint32_t)s, (uint32_t)zs.layer, (uint32_t)d);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// block-wide sum -> one atomic
+__device__ __forceinline__ void block_atomic_add(double v, double* dst, double* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    unsafeAtomicAdd(dst, t);
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------- Kuf (point-major)
+__global__ void rbf_kuf_kernel(const double* __restrict__ Xin, long P, long x_row0, const double* __restrict__ Z,
+                               const double* __restrict__ var, const double* __restrict__ ls, int M, int Mp, int Din,
+                               double* __restrict__ Kt) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * Mp) return;
+  const long p = idx / Mp;
+  const int m = (int)(idx % Mp);
+  double v = 0.0;
+  if (m < M) {
+    const double* x = Xin + (x_row0 + p) * Din;
+    const double* z = Z + (long)m * Din;
+    double r2 = 0.0;
+    for (int j = 0; j < Din; ++j) {
+      const double d = (x[j] - z[j]) / ls[j];
+      r2 += d * d;
+    }
+    v = var[0] * exp(-0.5 * r2);
+  }
+  Kt[idx] = v;
+}
+
+hipError_t rbf_kuf(hipStream_t st, const double* Xin, long P, long x_row0, const double* Z, const double* var,
+                   const double* ls, int M, int Mp, int Din, double* Kt) {
+  const long n = P * Mp;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(rbf_kuf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M,
+                     Mp, Din, Kt);
+  LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------- var / mean / sample
+// One wave per point.  var = k_diag - |c|^2 + |W_d^T c|^2  (triangular form of layers.py:254-276),
+// mean = c^T u_d + mean_function(x)  (layers.py:249,278),  F = mean + z sqrt(var + jitter)  (utils.py:41).
+__global__ __launch_bounds__(256) void var_mean_sample_kernel(
+    const double* __restrict__ Ct, const double* __restrict__ Tt, const double* __restrict__ u,
+    const double* __restrict__ Xin, long x_row0, long P, long Nc, int S, int dedup, int M, int Mp, int Din, int D,
+    const double* __restrict__ kvar, int mean_kind, const double* __restrict__ meanW, const double* __restrict__ meanb,
+    ZSource zsrc, long n_chunk0, double* __restrict__ mean, double* __restrict__ var, double* __restrict__ F) {
+  const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P) return;
+  const int lane = threadIdx.x & 63;
+  const double* c = Ct + p * Mp;
+  double cn = 0.0;
+  for (int m = lane; m < Mp; m += 64) { const double v = c[m]; cn += v * v; }
+  cn = wave_sum(cn);
+  const double* x = Xin + (x_row0 + p) * Din;
+  const double kv = kvar[0];
+  for (int d = 0; d < D; ++d) {
+    const double* t = Tt + (p * D + d) * Mp;
+    double tn = 0.0, mu = 0.0;
+    for (int m = lane; m < Mp; m += 64) {
+      const double tv = t[m];
+      tn += tv * tv;
+      if (m < M) mu += c[m] * u[(long)m * D + d];
+    }
+    tn = wave_sum(tn);
+    mu = wave_sum(mu);
+    double mf = 0.0;
+    if (mean_kind == 1) mf = x[d];
+    else if (mean_kind == 2) {
+      for (int j = 0; j < Din; ++j) mf += x[j] * meanW[(long)j * D + d];
+      mf += meanb[d];
+    }
+    const double mv = mu + mf, vv = kv - cn + tn;
+    if (lane == 0) { mean[p * D + d] = mv; var[p * D + d] = vv; }
+    if (F) {
+      const double sd = sqrt(vv + kJitter);
+      if (dedup) {
+        for (int s = lane; s < S; s += 64)
+          F[((long)s * Nc + p) * D + d] = mv + draw_z(zsrc, s, n_chunk0 + p, d, D) * sd;
+      } else if (lane == 0) {
+        const int s = (int)(p / Nc);
+        const long i = p % Nc;
+        F[p * D + d] = mv + draw_z(zsrc, s, n_chunk0 + i, d, D) * sd;
+      }
+    }
+  }
+}
+
+hipError_t var_mean_sample(hipStream_t st, const double* Ct, const double* Tt, const double* u, const double* Xin,
+                           long x_row0, long P, long Nc, int S, int dedup, int M, int Mp, int Din, int D,
+                           const double* kvar, int mean_kind, const double* meanW, const double* meanb, ZSource zsrc,
+                           long n_chunk0, double* mean, double* var, double* F) {
+  if (P == 0) return hipSuccess;
+  hipLaunchKernelGGL(var_mean_sample_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, Ct, Tt, u, Xin, x_row0, P,
+                     Nc, S, dedup, M, Mp, Din, D, kvar, mean_kind, meanW, meanb, zsrc, n_chunk0, mean, var, F);
+  LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------- Gaussian likelihood
+// ELBO data term  sum_n mean_s VE   (dgp.py:79-87,96) and the seeds d/dmean, d/dvar of the backward.
+__global__ __launch_bounds__(256) void gauss_lik_kernel(const double* __restrict__ mean, const double* __restrict__ var,
+                                                        const double* __restrict__ Y, long y_row0, long Nc, int S,
+                                                        int dedup, int Dy, const double* __restrict__ lik_var,
+                                                        double* __restrict__ acc_elbo, double* __restrict__ acc_dlik,
+                                                        double* __restrict__ mbar, double* __restrict__ vbar,
+                                                        double* __restrict__ acc_dkvar) {
+  __shared__ double sh[4];
+  const long P = dedup ? Nc : (long)S * Nc;
+  const long total = P * Dy;
+  const double s2 = lik_var[0];
+  const double w = dedup ? 1.0 : 1.0 / (double)S;
+  double e = 0.0, dl = 0.0, dk = 0.0;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long p = idx / Dy;
+    const int d = (int)(idx % Dy);
+    const long i = p % Nc;
+    const double y = Y[(y_row0 + i) * Dy + d];
+    const double r = y - mean[idx], v = var[idx];
+    const double q = r * r + v;
+    e += w * (-0.91893853320467274178 - 0.5 * log(s2) - 0.5 * q / s2);
+    dl += w * (-0.5 / s2 + 0.5 * q / (s2 * s2));
+    if (mbar) {
+      mbar[idx] = w * r / s2;
+      const double vb = -0.5 * w / s2;
+      vbar[idx] = vb;
+      dk += vb;
+    }
+  }
+  block_atomic_add(e, acc_elbo, sh);
+  if (mbar) {
+    block_atomic_add(dl, acc_dlik, sh);
+    block_atomic_add(dk, acc_dkvar, sh);
+  }
+}
+
+hipError_t gauss_lik(hipStream_t st, const double* mean, const double* var, const double* Y, long y_row0, long Nc, int S,
+                     int dedup, int Dy, const double* lik_var, double* acc_elbo, double* acc_dlik, double* mbar,
+                     double* vbar, double* acc_dkvar) {
+  const long total = (dedup ? Nc : (long)S * Nc) * Dy;
+  if (total == 0) return hipSuccess;
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gauss_lik_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mean, var, Y, y_row0, Nc, S, dedup, Dy,
+                     lik_var, acc_elbo, acc_dlik, mbar, vbar, acc_dkvar);
+  LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------- fold dF into (mbar, vbar)
+// F = mean + z sqrt(var + eps):  mbar = dF,  vbar = dF z / (2 sqrt(var + eps));  summed over s when the
+// layer's mean/var are shared by all samples (first layer).
+__global__ __launch_bounds__(256) void fold_kernel(const double* __restrict__ Fbar, const double* __restrict__ var,
+                                                   long Nc, int S, int dedup, int D, ZSource zsrc, long n_chunk0,
+                                                   double* __restrict__ mbar, double* __restrict__ vbar,
+                                                   double* __restrict__ acc_dkvar) {
+  __shared__ double sh[4];
+  const long P = dedup ? Nc : (long)S * Nc;
+  const long total = P * D;
+  double dk = 0.0;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long p = idx / D;
+    const int d = (int)(idx % D);
+    const double inv = 0.5 / sqrt(var[idx] + kJitter);
+    double mb = 0.0, vb = 0.0;
+    if (dedup) {
+      for (int s = 0; s < S; ++s) {
+        const double fb = Fbar[((long)s * Nc + p) * D + d];
+        mb += fb;
+        vb += fb * draw_z(zsrc, s, n_chunk0 + p, d, D) * inv;
+      }
+    } else {
+      const int s = (int)(p / Nc);
+      const long i = p % Nc;
+      const double fb = Fbar[idx];
+      mb = fb;
+      vb = fb * draw_z(zsrc, s, n_chunk0 + i, d, D) * inv;
+    }
+    mbar[idx] = mb;
+    vbar[idx] = vb;
+    dk += vb;
+  }
+  block_atomic_add(dk, acc_dkvar, sh);
+}
+
+hipError_t fold_sample_grad(hipStream_t st, const double* Fbar, const double* var, long Nc, int S, int dedup, int D,
+                            ZSource zsrc, long n_chunk0, double* mbar, double* vbar, double* acc_dkvar) {
+  const long total = (dedup ? Nc : (long)S * Nc) * D;
+  if (total == 0) return hipSuccess;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Fbar, var, Nc, S, dedup, D, zsrc, n_chunk0,
+                     mbar, vbar, acc_dkvar);
+  LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------- sTt = 2 vbar * Tt
+__global__ void scale_T_kernel(double* __restrict__ Tt, const double* __restrict__ vbar, long rows, int Mp) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 2 doubles
+  const long half = Mp / 2;
+  if (idx >= rows * half) return;
+  const long r = idx / half;
+  d2_t* p = reinterpret_cast<d2_t*>(Tt) + idx;
+  const double s = 2.0 * vbar[r];
+  d2_t v = *p;
+  v[0] *= s;
+  v[1] *= s;
+  *p = v;
+}
+hipError_t scale_T(hipStream_t st, double* Tt, const double* vbar, long P, int Mp, int D) {
+  const long n = P * D * (Mp / 2);
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(scale_T_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Tt, vbar, P * D, Mp);
+  LAUNCH_CHECK();
+}
+
+// dC += u mbar^T - 2 (sum_d vbar) C      (SURVEY App. C step 3 in whitened form)
+__global__ void cbar_fix_kernel(double* __restrict__ Cbar, const double* __restrict__ Ct, const double* __restrict__ mbar,
+                                const double* __restrict__ vbar, const double* __restrict__ u, long P, int Mp, int D) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * Mp) return;
+  const long p = idx / Mp;
+  const int m = (int)(idx % Mp);
+  double w = 0.0, a = 0.0;
+  for (int d = 0; d < D; ++d) {
+    w += vbar[p * D + d];
+    a += mbar[p * D + d] * u[(long)m * D + d];
+  }
+  Cbar[idx] += a - 2.0 * w * Ct[idx];
+}
+hipError_t cbar_fix(hipStream_t st, double* Cbar, const double* Ct, const double* mbar, const double* vbar,
+                    const double* u, long P, int Mp, int D) {
+  const long n = P * Mp;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(cbar_fix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Cbar, Ct, mbar, vbar, u, P,
+                     Mp, D);
+  LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------- RBF backward (Kuf)
+// g = dK .* K;  dx_pj = sum_m g (z_mj - x_pj)/l_j^2 (+ mean-function path);  dz_mj -= sum_p g (z_mj - x_pj)/l_j^2;
+// dl_j += sum g (z_mj - x_pj)^2 / l_j^3;  dvar += sum g / var      
+// Persistent blocks: a tile of TP points of g is staged in LDS; the (m,j) sums are kept in LDS across
+// tiles and flushed once per block with one atomic per entry.
+__global__ __launch_bounds__(256) void rbf_kuf_bwd_kernel(
+    const double* __restrict__ Kbar, const double* __restrict__ Kt, const double* __restrict__ Xin, long x_row0, long P,
+    const double* __restrict__ Z, const double* __restrict__ var, const double* __restrict__ ls, int M, int Mp, int Din,
+    int D, int mean_kind, const double* __restrict__ meanW, const double* __restrict__ mbar, int want_xbar,
+    double* __restrict__ xbar, double* __restrict__ acc_dZ, double* __restrict__ acc_dls, double* __restrict__ acc_dvar,
+    int TP, int lds_sums) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int ldg = Mp + 2;
+  double* g = sm;                       // [TP][Mp+2]
+  double* xs = g + (long)TP * ldg;      // [TP][Din]
+  double* zsum = xs + (long)TP * Din;   // [M*Din]   (only when lds_sums)
+  double* lsum = zsum + (lds_sums ? (long)M * Din : 0);
+  __shared__ double sh[4];
+  const int tid = threadIdx.x;
+  const long npair = (long)M * Din;
+  if (lds_sums)
+    for (long q = tid; q < npair; q += 256) { zsum[q] = 0.0; lsum[q] = 0.0; }
+  double vacc = 0.0;
+  const long ntile = (P + TP - 1) / TP;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const long p0 = tile * TP;
+    const int np = (int)min((long)TP, P - p0);
+    __syncthreads();
+    for (long idx = tid; idx < (long)TP * Mp; idx += 256) {
+      const int pt = (int)(idx / Mp), m = (int)(idx % Mp);
+      double v = 0.0;
+      if (pt < np && m < M) v = Kbar[(p0 + pt) * Mp + m] * Kt[(p0 + pt) * Mp + m];
+      g[(long)pt * ldg + m] = v;
+      vacc += v;
+    }
+    for (int idx = tid; idx < TP * Din; idx += 256) {
+      const int pt = idx / Din, j = idx % Din;
+      xs[idx] = (pt < np) ? Xin[(x_row0 + p0 + pt) * Din + j] : 0.0;
+    }
+    __syncthreads();
+    // inducing-point side
+    for (long q = tid; q < npair; q += 256) {
+      const int m = (int)(q / Din), j = (int)(q % Din);
+      const double zmj = Z[q];
+      double za = 0.0, la = 0.0;
+      for (int pt = 0; pt < np; ++pt) {
+        const double gv = g[(long)pt * ldg + m];
+        const double dl = zmj - xs[pt * Din + j];
+        za += gv * dl;
+        la += gv * dl * dl;
+      }
+      if (lds_sums) { zsum[q] += za; lsum[q] += la; }
+      else {
+        const double l = ls[j];
+        unsafeAtomicAdd(acc_dZ + q, -za / (l * l));
+        unsafeAtomicAdd(acc_dls + j, la / (l * l * l));
+      }
+    }
+    // input side
+    if (want_xbar) {
+      for (int idx = tid; idx < np * Din; idx += 256) {
+        const int pt = idx / Din, j = idx % Din;
+        const double xv = xs[idx], l = ls[j];
+        double a = 0.0;
+        for (int m = 0; m < M; ++m) a += g[(long)pt * ldg + m] * (Z[(long)m * Din + j] - xv);
+        a /= (l * l);
+        const double* mb = mbar + (p0 + pt) * D;
+        if (mean_kind == 1) a += mb[j];
+        else if (mean_kind == 2)
+          for (int d = 0; d < D; ++d) a += meanW[(long)j * D + d] * mb[d];
+        xbar[(p0 + pt) * Din + j] = a;
+      }
+    }
+  }
+  __syncthreads();
+  if (lds_sums) {
+    for (long q = tid; q < npair; q += 256) {
+      const int j = (int)(q % Din);
+      const double l = ls[j];
+      unsafeAtomicAdd(acc_dZ + q, -zsum[q] / (l * l));
+      unsafeAtomicAdd(acc_dls + j, lsum[q] / (l * l * l));
+    }
+  }
+  block_atomic_add(vacc / var[0], acc_dvar, sh);
+}
+
+hipError_t rbf_kuf_bwd(hipStream_t st, const double* Kbar, const double* Kt, const double* Xin, long x_row0, long P,
+                       const double* Z, const double* var, const double* ls, int M, int Mp, int Din, int D, int mean_kind,
+                       const double* meanW, const double* mbar, int want_xbar, double* xbar, double* acc_dZ,
+                       double* acc_dls, double* acc_dvar) {
+  if (P == 0) return hipSuccess;
+  int TP = 32;
+  while (TP > 4 && (long)TP * (Mp + 2) * 8 > 65536) TP >>= 1;
+  const int lds_sums = ((long)M * Din * 16 <= 65536) ? 1 : 0;
+  const size_t lds = ((size_t)TP * (Mp + 2) + (size_t)TP * Din + (lds_sums ? 2 * (size_t)M * Din : 0)) * 8;
+  const long ntile = (P + TP - 1) / TP;
+  long blocks = ntile < 1024 ? ntile : 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kuf_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024 - 64);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(rbf_kuf_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, st, Kbar, Kt, Xin, x_row0, P, Z, var, ls,
+                     M, Mp, Din, D, mean_kind, meanW, mbar, want_xbar, xbar, acc_dZ, acc_dls, acc_dvar, TP, lds_sums);
+  LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------- output helpers
+__global__ void expand_rows_kernel(const double* __restrict__ src, long Nc, int S, int D, int dedup,
+                                   double* __restrict__ dst, long Ntot, long n0) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)S * Nc * D;
+  if (idx >= total) return;
+  const int d = (int)(idx % D);
+  const long r = idx / D;
+  const long s = r / Nc, i = r % Nc;
+  dst[(s * Ntot + n0 + i) * D + d] = src[(dedup ? i : r) * D + d];
+}
+hipError_t expand_rows(hipStream_t st, const double* src, long Nc, int S, int D, int dedup, double* dst, long Ntot,
+                       long n0) {
+  const long n = (long)S * Nc * D;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, Nc, S, D, dedup, dst,
+                     Ntot, n0);
+  LAUNCH_CHECK();
+}
+
+__global__ void add_scalar_kernel(double* __restrict__ v, long n, const double* __restrict__ s) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] += s[0];
+}
+hipError_t lik_predict_var(hipStream_t st, double* var, long n, const double* lik_var) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(add_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, var, n, lik_var);
+  LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------- unit-level helpers
+__global__ void normals_kernel(ZSource z, int S, long N, int D, double* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)S * N * D) return;
+  const int d = (int)(idx % D);
+  const long r = idx / D;
+  out[idx] = draw_z(z, (int)(r / N), r % N, d, D);
+}
+hipError_t launch_normals(hipStream_t st, ZSource z, int S, long N, int D, double* out) {
+  const long n = (long)S * N * D;
+  hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, S, N, D, out);
+  LAUNCH_CHECK();
+}
+
+// issue-rate micro-benchmark of v_mfma_f64_16x16x4_f64: 8 independent accumulators per wave
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, double* __restrict__ sink) {
+  d4_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + threadIdx.x * 1e-3, b = 0.5 - threadIdx.x * 1e-3;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    a += 1e-9;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  sink[(long)blockIdx.x * 256 + threadIdx.x] = s;
+}
+hipError_t launch_mfma_peak(hipStream_t st, int blocks, int iters, double* sink) {
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, iters, sink);
+  LAUNCH_CHECK();
+}
+
+}  // namespace dgp

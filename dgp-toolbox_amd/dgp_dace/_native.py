@@ -1,0 +1,300 @@
+"""ctypes binding of libdgp_hip.so (include/dgp_abi.h).
+
+There is no CPU fallback: if the shared library is missing or no gfx950 device is usable, the
+first compute call raises ``NativeUnavailable`` — the reference would have run TensorFlow on the
+CPU here (dgp.py:102-109); this engine deliberately does not.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("DGP_HIP_LIB", os.path.join(os.path.dirname(_HERE), "libdgp_hip.so"))
+
+DGP_OK, ERR_INVALID, ERR_HIP, ERR_NOT_PD, ERR_NO_DEVICE, ERR_NONFINITE = 0, -1, -2, -3, -4, -5
+
+# every symbol include/dgp_abi.h declares
+SYMBOLS = [
+    "dgp_create", "dgp_destroy", "dgp_last_error", "dgp_sync", "dgp_device_info", "dgp_model_set", "dgp_param_count",
+    "dgp_params_get", "dgp_params_set", "dgp_data_set", "dgp_set_workspace_limit", "dgp_elbo", "dgp_propagate",
+    "dgp_grad_partial", "dgp_acc_info", "dgp_acc_bind", "dgp_grad_finish", "dgp_grad_get", "dgp_last_elbo",
+    "dgp_adam_reset", "dgp_adam_step", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_dev_gemm",
+    "dgp_dev_chol", "dgp_dev_trinv", "dgp_dev_normals", "dgp_dev_mfma_peak",
+]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libdgp_hip error {code}: {msg}")
+        self.code = code
+
+
+class NativeUnavailable(RuntimeError):
+    pass
+
+
+class NotPositiveDefinite(NativeError):
+    """Cholesky met a non-positive pivot (the reference surfaces tf InvalidArgumentError)."""
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("D_in", C.c_int32), ("D_out", C.c_int32), ("M", C.c_int32), ("white", C.c_int32),
+                ("kernel_kind", C.c_int32), ("mean_kind", C.c_int32)]
+
+
+_dp = C.POINTER(C.c_double)
+_dpp = C.POINTER(_dp)
+_lib = None
+
+
+def load():
+    """Load the shared library (no device is touched)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeUnavailable(
+            f"{LIB_PATH} not found: build it with `make -C dgp-toolbox_amd/csrc` (hipcc, gfx950). "
+            "There is no CPU fallback for the DGP hot path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+    sig = {
+        "dgp_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+        "dgp_destroy": (None, [vp]),
+        "dgp_last_error": (C.c_char_p, [vp]),
+        "dgp_sync": (C.c_int, [vp]),
+        "dgp_device_info": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(i64)]),
+        "dgp_model_set": (C.c_int, [vp, C.c_int, C.POINTER(LayerDesc), _dp, i64, _dp, i64]),
+        "dgp_param_count": (i64, [vp]),
+        "dgp_params_get": (C.c_int, [vp, _dp]),
+        "dgp_params_set": (C.c_int, [vp, _dp]),
+        "dgp_data_set": (C.c_int, [vp, _dp, _dp, i64, i32, i32, i64]),
+        "dgp_set_workspace_limit": (C.c_int, [vp, i64]),
+        "dgp_elbo": (C.c_int, [vp, i32, u64, _dpp, _dp, _dp]),
+        "dgp_propagate": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dpp, _dpp, _dpp, i32]),
+        "dgp_grad_partial": (C.c_int, [vp, i32, u64, _dpp]),
+        "dgp_acc_info": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
+        "dgp_acc_bind": (C.c_int, [vp, vp]),
+        "dgp_grad_finish": (C.c_int, [vp, _dp]),
+        "dgp_grad_get": (C.c_int, [vp, _dp]),
+        "dgp_last_elbo": (C.c_int, [vp, _dp]),
+        "dgp_adam_reset": (C.c_int, [vp]),
+        "dgp_adam_step": (C.c_int, [vp, dbl, dbl, dbl, dbl, C.POINTER(C.c_uint8)]),
+        "dgp_natgrad_step": (C.c_int, [vp, dbl, C.POINTER(C.c_uint8)]),
+        "dgp_prof_enable": (C.c_int, [vp, i32]),
+        "dgp_prof_read": (C.c_int, [vp, i32, _dp, C.POINTER(i64), _dp, _dp]),
+        "dgp_dev_gemm": (C.c_int, [vp, i32, i64, i64, i64, _dp, i64, _dp, i64, _dp, i64, dbl, i32, i32, i32, i64, i32, _dp]),
+        "dgp_dev_chol": (C.c_int, [vp, _dp, i32, i32]),
+        "dgp_dev_trinv": (C.c_int, [vp, _dp, _dp, i32, i32]),
+        "dgp_dev_normals": (C.c_int, [vp, u64, i32, i32, i64, i64, i32, _dp]),
+        "dgp_dev_mfma_peak": (C.c_int, [vp, i32, _dp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr_array(arrs):
+    """host list of arrays (or None entries) -> (double*[]), keeping the arrays alive"""
+    T = _dp * len(arrs)
+    return T(*[(_ptr(a) if a is not None else None) for a in arrs])
+
+
+class Context:
+    """Owns one dgp_ctx (one device, one stream)."""
+
+    def __init__(self, device=0, stream=None):
+        lib = load()
+        h = C.c_void_p()
+        rc = lib.dgp_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc == ERR_NO_DEVICE:
+            raise NativeUnavailable("no usable AMD GPU (gfx950) visible to HIP: the DGP hot path has no CPU fallback")
+        if rc != DGP_OK:
+            raise NativeError(rc, "dgp_create failed")
+        self._h, self._lib, self.device = h, lib, int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dgp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc == DGP_OK:
+            return
+        msg = self._lib.dgp_last_error(self._h).decode()
+        if rc == ERR_NOT_PD:
+            raise NotPositiveDefinite(rc, msg)
+        raise NativeError(rc, msg)
+
+    # ---- model / data ---------------------------------------------------------------------
+    def model_set(self, descs, flat_params, mean_params):
+        arr = (LayerDesc * len(descs))(*[LayerDesc(*d) for d in descs])
+        fp = _c(flat_params)
+        mp = _c(mean_params) if mean_params is not None and len(mean_params) else np.zeros(0)
+        self._chk(self._lib.dgp_model_set(self._h, len(descs), arr, _ptr(fp), fp.size,
+                                          _ptr(mp) if mp.size else None, mp.size))
+        self.n_layers = len(descs)
+        self.douts = [d[1] for d in descs]
+
+    def param_count(self):
+        return int(self._lib.dgp_param_count(self._h))
+
+    def params_get(self):
+        out = np.empty(self.param_count())
+        self._chk(self._lib.dgp_params_get(self._h, _ptr(out)))
+        return out
+
+    def params_set(self, flat):
+        flat = _c(flat)
+        assert flat.size == self.param_count()
+        self._chk(self._lib.dgp_params_set(self._h, _ptr(flat)))
+
+    def data_set(self, X, Y, n_global_offset=0):
+        X, Y = _c(X), _c(Y)
+        self._chk(self._lib.dgp_data_set(self._h, _ptr(X), _ptr(Y), X.shape[0], X.shape[1], Y.shape[1],
+                                         int(n_global_offset)))
+
+    def set_workspace_limit(self, nbytes):
+        self._chk(self._lib.dgp_set_workspace_limit(self._h, int(nbytes)))
+
+    # ---- forward --------------------------------------------------------------------------
+    def _zs(self, zs):
+        if zs is None:
+            return None, None
+        keep = [_c(z) for z in zs]
+        return _ptr_array(keep), keep
+
+    def elbo(self, S, seed=0, zs=None):
+        zp, keep = self._zs(zs)
+        a, b = C.c_double(), C.c_double()
+        self._chk(self._lib.dgp_elbo(self._h, int(S), int(seed) & (2 ** 64 - 1), zp, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def propagate(self, Xnew, S, seed=0, zs=None, want=(True, True, True), add_lik_var=False):
+        Xnew = _c(Xnew)
+        Nn = Xnew.shape[0]
+        zp, keep = self._zs(zs)
+        outs = []
+        for w in want:
+            outs.append([np.empty((S, Nn, d)) if w else None for d in self.douts])
+        ptrs = [_ptr_array(o) for o in outs]
+        self._chk(self._lib.dgp_propagate(self._h, _ptr(Xnew), Nn, int(S), int(seed) & (2 ** 64 - 1), zp, ptrs[0],
+                                          ptrs[1], ptrs[2], 1 if add_lik_var else 0))
+        return outs
+
+    # ---- backward + optimisers --------------------------------------------------------------
+    def grad_partial(self, S, seed=0, zs=None):
+        zp, keep = self._zs(zs)
+        self._chk(self._lib.dgp_grad_partial(self._h, int(S), int(seed) & (2 ** 64 - 1), zp))
+
+    def acc_info(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self._lib.dgp_acc_info(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def acc_bind(self, dev_ptr):
+        self._chk(self._lib.dgp_acc_bind(self._h, C.c_void_p(dev_ptr) if dev_ptr else None))
+
+    def grad_finish(self, want_elbo=False):
+        if want_elbo:
+            e = C.c_double()
+            self._chk(self._lib.dgp_grad_finish(self._h, C.byref(e)))
+            return e.value
+        self._chk(self._lib.dgp_grad_finish(self._h, None))
+        return None
+
+    def grad_get(self):
+        out = np.empty(self.param_count())
+        self._chk(self._lib.dgp_grad_get(self._h, _ptr(out)))
+        return out
+
+    def last_elbo(self):
+        e = C.c_double()
+        self._chk(self._lib.dgp_last_elbo(self._h, C.byref(e)))
+        return e.value
+
+    def adam_reset(self):
+        self._chk(self._lib.dgp_adam_reset(self._h))
+
+    def adam_step(self, lr, beta_1, beta_2, epsilon, trainable):
+        t = (C.c_uint8 * len(trainable))(*[1 if x else 0 for x in trainable])
+        self._chk(self._lib.dgp_adam_step(self._h, lr, beta_1, beta_2, epsilon, t))
+
+    def natgrad_step(self, gamma, layer_mask):
+        t = (C.c_uint8 * len(layer_mask))(*[1 if x else 0 for x in layer_mask])
+        self._chk(self._lib.dgp_natgrad_step(self._h, gamma, t))
+
+    def sync(self):
+        self._chk(self._lib.dgp_sync(self._h))
+
+    # ---- measurement ------------------------------------------------------------------------
+    def device_info(self):
+        buf = C.create_string_buffer(256)
+        cu, mem = C.c_int(), C.c_int64()
+        self._chk(self._lib.dgp_device_info(self._h, buf, 256, C.byref(cu), C.byref(mem)))
+        return buf.value.decode(), cu.value, mem.value
+
+    def prof_enable(self, on=True):
+        self._chk(self._lib.dgp_prof_enable(self._h, 1 if on else 0))
+
+    def prof_read(self):
+        ms, fl, by = np.zeros(4), np.zeros(4), np.zeros(4)
+        ln = np.zeros(4, dtype=np.int64)
+        self._chk(self._lib.dgp_prof_read(self._h, 4, _ptr(ms), ln.ctypes.data_as(C.POINTER(C.c_int64)), _ptr(fl), _ptr(by)))
+        names = ["mfma_contractions", "per_point_streaming", "small_matrix_chain", "adam"]
+        return {n: {"ms": ms[i], "launches": int(ln[i]), "alg_flops": fl[i], "alg_bytes": by[i]} for i, n in enumerate(names)}
+
+    # ---- unit-level hooks -------------------------------------------------------------------
+    def dev_gemm(self, op, A, B, C0=None, alpha=1.0, beta=0, splits=1, tri=0, triblk=0, repeats=0):
+        A, B = _c(A), _c(B)
+        opi = {"NN": 0, "NT": 1, "TN": 2}[op]
+        M = A.shape[1] if opi == 2 else A.shape[0]
+        K = A.shape[0] if opi == 2 else A.shape[1]
+        N = B.shape[0] if opi == 1 else B.shape[1]
+        Cm = np.zeros((M, N)) if C0 is None else _c(C0).copy()
+        ms = C.c_double()
+        self._chk(self._lib.dgp_dev_gemm(self._h, opi, M, N, K, _ptr(A), A.shape[1], _ptr(B), B.shape[1], _ptr(Cm), N,
+                                         alpha, beta, splits, tri, triblk, repeats, C.byref(ms)))
+        return (Cm, ms.value) if repeats else Cm
+
+    def dev_chol(self, A):
+        A = _c(A).copy()
+        b = 1 if A.ndim == 2 else A.shape[0]
+        self._chk(self._lib.dgp_dev_chol(self._h, _ptr(A), A.shape[-1], b))
+        return A
+
+    def dev_trinv(self, L):
+        L = _c(L)
+        X = np.empty_like(L)
+        b = 1 if L.ndim == 2 else L.shape[0]
+        self._chk(self._lib.dgp_dev_trinv(self._h, _ptr(L), _ptr(X), L.shape[-1], b))
+        return X
+
+    def dev_normals(self, seed, layer, S, n0, N, D):
+        out = np.empty((S, N, D))
+        self._chk(self._lib.dgp_dev_normals(self._h, int(seed) & (2 ** 64 - 1), layer, S, n0, N, D, _ptr(out)))
+        return out
+
+    def dev_mfma_peak(self, iters=20000):
+        t = C.c_double()
+        self._chk(self._lib.dgp_dev_mfma_peak(self._h, iters, C.byref(t)))
+        return t.value

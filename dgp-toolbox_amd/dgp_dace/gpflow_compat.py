@@ -1,0 +1,186 @@
+"""Duck-typed stand-ins for the handful of GPflow objects the DGP constructor is handed.
+
+GPflow/TensorFlow are not a dependency of this engine.  The reference's callers build kernels,
+likelihood and mean functions with GPflow (nb_DGP_regression cell 17: ``RBF(lengthscales=[1]*d,
+variance=1.0)``; SO_BO.py:240 ``gpflow.kernels.SquaredExponential``; ``gpflow.likelihoods.Gaussian()``)
+and touch parameters through ``.numpy()`` / ``.assign()`` / ``gpflow.set_trainable`` (dgp.py:268-269,
+316-322).  These classes offer exactly that surface; real GPflow objects are accepted too (they are
+read by attribute name, see ``kernel_from_any`` / ``likelihood_variance_from_any``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class TensorLike(np.ndarray):
+    """ndarray that also answers ``.numpy()`` like the tf.Tensor the reference returns."""
+
+    def numpy(self):
+        return np.asarray(self)
+
+
+def as_tensor(a):
+    return np.asarray(a, dtype=np.float64).view(TensorLike)
+
+
+class Parameter:
+    """Value holder with the gpflow.Parameter surface the reference's code paths use."""
+
+    def __init__(self, value, name=None, transform="identity", trainable=True):
+        self._value = np.array(value, dtype=np.float64)
+        self.name = name
+        self.transform = transform          # "identity" | "softplus" | "softplus_shift" | "tril"
+        self.trainable = bool(trainable)
+        self._owner = None                  # set by DGP: object with _before_read() / _after_write()
+
+    # -- gpflow surface --
+    def numpy(self):
+        if self._owner is not None:
+            self._owner._before_read()
+        return self._value.copy()
+
+    def assign(self, value):
+        value = np.asarray(value.numpy() if hasattr(value, "numpy") else value, dtype=np.float64)
+        if self._owner is not None:
+            self._owner._before_read()
+        if value.shape != self._value.shape:
+            value = np.broadcast_to(value, self._value.shape)
+        self._value = np.array(value, dtype=np.float64)
+        if self.transform == "tril":
+            self._value = np.tril(self._value)
+        if self._owner is not None:
+            self._owner._after_write()
+        return self
+
+    @property
+    def shape(self):
+        return self._value.shape
+
+    def __array__(self, dtype=None, copy=None):
+        v = self.numpy()
+        return v.astype(dtype) if dtype is not None else v
+
+    def __mul__(self, o):
+        return self.numpy() * np.asarray(o)
+
+    __rmul__ = __mul__
+
+    def __add__(self, o):
+        return self.numpy() + np.asarray(o)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self.numpy() - np.asarray(o)
+
+    def __truediv__(self, o):
+        return self.numpy() / np.asarray(o)
+
+    def __repr__(self):
+        return f"Parameter(name={self.name!r}, shape={self._value.shape}, transform={self.transform}, trainable={self.trainable})"
+
+
+def set_trainable(obj, flag):
+    """gpflow.set_trainable for a Parameter or any object holding Parameters."""
+    if isinstance(obj, Parameter):
+        obj.trainable = bool(flag)
+        return
+    for v in vars(obj).values():
+        if isinstance(v, Parameter):
+            v.trainable = bool(flag)
+
+
+def _val(p):
+    return np.asarray(p.numpy() if hasattr(p, "numpy") else p, dtype=np.float64)
+
+
+class SquaredExponential:
+    """gpflow.kernels.SquaredExponential: K = variance * exp(-0.5 * |x/l - x'/l|^2), K_diag = variance."""
+
+    kind = "rbf"
+
+    def __init__(self, variance=1.0, lengthscales=1.0, **_):
+        self.variance = Parameter(np.asarray(variance, dtype=np.float64).reshape(()), "variance", "softplus")
+        self.lengthscales = Parameter(np.atleast_1d(np.asarray(lengthscales, dtype=np.float64)), "lengthscales",
+                                      "softplus")
+
+
+RBF = SquaredExponential
+
+
+class Gaussian:
+    """gpflow.likelihoods.Gaussian: variance with the Softplus + Shift(1e-6) transform."""
+
+    def __init__(self, variance=1.0, **_):
+        self.variance = Parameter(np.asarray(variance, dtype=np.float64).reshape(()), "variance", "softplus_shift")
+
+
+class Zero:
+    kind = "zero"
+
+
+class Identity:
+    kind = "identity"
+
+
+class Linear:
+    """gpflow.mean_functions.Linear(A, b): X @ A + b, b defaults to zeros(1)."""
+
+    kind = "linear"
+
+    def __init__(self, A=None, b=None):
+        A = np.ones((1, 1)) if A is None else np.asarray(A, dtype=np.float64)
+        b = np.zeros(1) if b is None else np.asarray(b, dtype=np.float64)
+        self.A = Parameter(A, "A")
+        self.b = Parameter(b, "b")
+
+
+class kernels:           # `from dgp_dace.gpflow_compat import kernels; kernels.RBF(...)`
+    SquaredExponential = SquaredExponential
+    RBF = SquaredExponential
+
+
+class likelihoods:
+    Gaussian = Gaussian
+
+
+class mean_functions:
+    Zero, Identity, Linear = Zero, Identity, Linear
+
+
+def kernel_from_any(k, input_dim):
+    """Accept our stand-in or a real gpflow kernel; only the squared exponential is on this path."""
+    if isinstance(k, SquaredExponential):
+        if k.lengthscales.shape == (1,) and input_dim > 1:       # isotropic -> ARD storage
+            k.lengthscales = Parameter(np.full(input_dim, k.lengthscales._value[0]), "lengthscales", "softplus")
+        return k
+    name = type(k).__name__
+    if name not in ("SquaredExponential", "RBF"):
+        raise NotImplementedError(
+            f"kernel {name}: only the squared-exponential (RBF) kernel is implemented on the HIP path "
+            "(Matern32/52 of SO_BO.py:194-197 are listed as a next row in DESIGN.md)")
+    ls = np.atleast_1d(_val(k.lengthscales))
+    if ls.size == 1 and input_dim > 1:
+        ls = np.full(input_dim, ls[0])
+    return SquaredExponential(variance=_val(k.variance), lengthscales=ls)
+
+
+def likelihood_from_any(lik):
+    if isinstance(lik, Gaussian):
+        return lik
+    if type(lik).__name__ != "Gaussian":
+        raise NotImplementedError("only the Gaussian likelihood is implemented (the reference's DGP callers use no other)")
+    return Gaussian(variance=_val(lik.variance))
+
+
+def mean_function_from_any(mf):
+    if mf is None:
+        return Zero()
+    kind = getattr(mf, "kind", None) or type(mf).__name__.lower()
+    if kind == "zero":
+        return mf if isinstance(mf, Zero) else Zero()
+    if kind == "identity":
+        return mf if isinstance(mf, Identity) else Identity()
+    if kind == "linear":
+        return mf if isinstance(mf, Linear) else Linear(_val(mf.A), _val(mf.b))
+    raise NotImplementedError(f"mean function {type(mf).__name__}")

@@ -1,0 +1,71 @@
+"""Data-point sharding across the GPUs of one node (one process per GPU, torch.distributed / RCCL).
+
+The reference has no multi-device code at all; this is new.  The ELBO data term
+and every gradient are sums over data points (dgp.py:87,96), so rank r keeps the points
+[r*N/W, (r+1)*N/W) with all S samples of each point, computes its partial sums into one contiguous
+fp64 buffer (dgp_grad_partial), and a single all-reduce(sum) of that buffer over xGMI precedes the
+replicated small-matrix chain and parameter update.  The Monte-Carlo normals are keyed by the
+global point index, so the result does not depend on the number of ranks (up to summation order).
+torch is used for the process group, the device buffer and the collective only.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+
+def shard_bounds(N, rank, world):
+    """Contiguous, balanced split of N points: rank r owns [lo, hi)."""
+    return (rank * N) // world, ((rank + 1) * N) // world
+
+
+class Dist:
+    def __init__(self, torch, dist):
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.local_rank = int(os.environ.get("LOCAL_RANK", self.rank))
+        self.on_gpu = dist.get_backend() == "nccl"
+        self._stream = None
+
+    def shard(self, N):
+        return shard_bounds(N, self.rank, self.world)
+
+    def stream_handle(self, dev):
+        """A torch-owned HIP stream the native context launches on, so collectives are ordered with the kernels."""
+        if not self.on_gpu:
+            return None
+        self.torch.cuda.set_device(dev)
+        self._stream = self.torch.cuda.Stream(device=dev)
+        return self._stream.cuda_stream
+
+    def device_buffer(self, n, dev):
+        device = f"cuda:{dev}" if self.on_gpu else "cpu"
+        return self.torch.zeros(int(n), dtype=self.torch.float64, device=device)
+
+    def all_reduce_(self, t):
+        """In-place sum over ranks of the partial-sum buffer (RCCL ring over xGMI on GPUs)."""
+        if self._stream is not None:
+            with self.torch.cuda.stream(self._stream):
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t
+
+    def all_reduce_scalar(self, v, dev=0):
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=(f"cuda:{dev}" if self.on_gpu else "cpu"))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def current():
+    """The active process group wrapper, or None when running single-process."""
+    if "torch" not in sys.modules:
+        return None
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() <= 1:
+        return None
+    return Dist(torch, dist)

@@ -1,0 +1,127 @@
+/* libdgp_hip.so — C-ABI of the MI355X-native doubly-stochastic DGP engine.
+ *
+ * The reference (Hebbalali/dgp-toolbox) has no native/FFI boundary: its hot path is reached through
+ * the Python object API of dgp_dace.models.dgp.DGP and executed by TensorFlow/GPflow.  This header
+ * is the boundary the build introduces underneath that API; each entry point names the reference
+ * interface it replaces (file:line under the reference root).  Plain C types only: host pointers
+ * are owned by the caller for the duration of the call; the context owns all device memory and one
+ * HIP stream (or borrows the caller's); nothing throws across the ABI.  Every function returns 0 on
+ * success or a negative dgp_status; the message is available from dgp_last_error().  A context is
+ * bound to one device and is not thread-safe (one context per device per process).
+ *
+ * All arrays are fp64, C-contiguous (row-major), exactly as the reference's NumPy inputs
+ * (layer_initializations.py:34) and tf.float64 outputs (layers.py:79).
+ */
+#ifndef DGP_ABI_H
+#define DGP_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dgp_ctx dgp_ctx;
+
+enum dgp_status {
+  DGP_OK = 0,
+  DGP_ERR_INVALID = -1,   /* bad argument / call order                                      */
+  DGP_ERR_HIP = -2,       /* HIP runtime error (message has hipGetErrorString)              */
+  DGP_ERR_NOT_PD = -3,    /* Cholesky met a non-positive pivot (TF: InvalidArgumentError)   */
+  DGP_ERR_NO_DEVICE = -4, /* no usable gfx950 device: the library has no CPU fallback       */
+  DGP_ERR_NONFINITE = -5  /* NaN/Inf in the ELBO (TF would propagate NaN silently)          */
+};
+
+enum dgp_kernel_kind { DGP_KERNEL_RBF = 0 };                 /* gpflow.kernels.SquaredExponential (ARD) */
+enum dgp_mean_kind { DGP_MEAN_ZERO = 0, DGP_MEAN_IDENTITY = 1, DGP_MEAN_LINEAR = 2 };
+
+/* One SVGP_Layer (layers.py:181-224): kernel on D_in inputs, M inducing points, D_out outputs. */
+typedef struct dgp_layer_desc {
+  int32_t D_in, D_out, M;
+  int32_t white;        /* layers.py:181 `white=`                        */
+  int32_t kernel_kind;  /* dgp_kernel_kind                                */
+  int32_t mean_kind;    /* dgp_mean_kind (layer_initializations.py:41-55) */
+} dgp_layer_desc;
+
+/* ---- lifetime --------------------------------------------------------------------------------- */
+/* `hip_stream`: a hipStream_t to launch on (e.g. torch's current stream), or NULL to create one. */
+int dgp_create(int device, void* hip_stream, dgp_ctx** out);
+void dgp_destroy(dgp_ctx* ctx);
+const char* dgp_last_error(const dgp_ctx* ctx);
+int dgp_sync(dgp_ctx* ctx);                 /* hipStreamSynchronize + deferred error flags */
+int dgp_device_info(dgp_ctx* ctx, char* name_out, int name_len, int* cu_count, int64_t* hbm_bytes);
+
+/* ---- model: replaces DGP.__init__ / init_layers_linear / SVGP_Layer.__init__ state
+ *      (dgp.py:245-254, layer_initializations.py:24-68, layers.py:181-224).
+ * flat_params packs the *constrained* values, per layer in this order:
+ *   Z[M*D_in], kern.variance[1], kern.lengthscales[D_in], q_mu[M*D_out], q_sqrt[D_out*M*M] (dense,
+ *   lower-triangular), and after the last layer likelihood.variance[1].
+ * mean_params packs, for every layer with DGP_MEAN_LINEAR, A[D_in*D_out] then b[D_out].          */
+int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, const double* flat_params,
+                  int64_t n_params, const double* mean_params, int64_t n_mean_params);
+int64_t dgp_param_count(const dgp_ctx* ctx);
+int dgp_params_get(dgp_ctx* ctx, double* flat_out);        /* Parameter.numpy()  (dgp.py:316-322 users) */
+int dgp_params_set(dgp_ctx* ctx, const double* flat_in);   /* Parameter.assign() (dgp.py:268-269)       */
+
+/* ---- data: replaces `self.data = (X, Y)` (dgp.py:254; reassigned by SO_BO.py:288).
+ * n_global_offset = global index of local point 0 (non-zero only for a rank that owns a shard);
+ * it only keys the counter-based normals so that draws do not depend on the sharding.            */
+int dgp_data_set(dgp_ctx* ctx, const double* X, const double* Y, int64_t N, int32_t D, int32_t Dy,
+                 int64_t n_global_offset);
+int dgp_set_workspace_limit(dgp_ctx* ctx, int64_t bytes);  /* bound on per-chunk intermediates in HBM */
+
+/* ---- forward: replaces DGP_Base.ELBO / ELBO_closure (dgp.py:89-109).
+ * zs: NULL (draw N(0,1) from Philox4x32-10 keyed by seed) or n_layers host pointers [S,N,D_out_l]
+ * (the reference's `propagate(..., zs=)`, dgp.py:34,54-57).  Outputs: data term and sum of KLs;
+ * ELBO = *data_term - *kl (scale == 1, dgp.py:95-99).                                            */
+int dgp_elbo(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs, double* data_term, double* kl);
+
+/* replaces DGP_Base.propagate / predict_f / predict_y (dgp.py:34-77,113-124): every output pointer
+ * array has n_layers entries [S,Nn,D_out_l] (entries or whole arrays may be NULL = not wanted).
+ * add_lik_var != 0 adds likelihood.variance to the last layer's Fvar (Gaussian.predict_mean_and_var). */
+int dgp_propagate(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
+                  double* const* Fs, double* const* Fmeans, double* const* Fvars, int32_t add_lik_var);
+
+/* ---- backward + optimisers: replaces the tf.GradientTape / Adam / NaturalGradient loop bodies
+ *      (dgp.py:270-276, 326-345).  Split so that a multi-GPU host can all-reduce between the stages:
+ *   dgp_grad_partial : this rank's sums over its data points (ELBO data term + every point-sum the
+ *                      gradient needs) into one contiguous device buffer
+ *   dgp_acc_info     : that buffer (device pointer, length in doubles) for an in-place all-reduce
+ *   dgp_grad_finish  : small-matrix chain (Cholesky backward, KL gradient) -> d ELBO / d params     */
+int dgp_grad_partial(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs);
+int dgp_acc_info(dgp_ctx* ctx, void** device_ptr, int64_t* n_doubles);
+int dgp_acc_bind(dgp_ctx* ctx, void* external_device_ptr);   /* use caller-owned device memory for it */
+int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out /* NULL = do not synchronise */);
+int dgp_grad_get(dgp_ctx* ctx, double* flat_grad_out);       /* d ELBO / d constrained params, same packing */
+int dgp_last_elbo(dgp_ctx* ctx, double* elbo_out);           /* ELBO of the last dgp_grad_finish (synchronises) */
+
+/* tf.optimizers.Adam on the unconstrained variables (dgp.py:267,276; 311,333,342).
+ * trainable: 5*n_layers+1 flags in the order [Z, variance, lengthscales, q_mu, q_sqrt]*, lik variance
+ * (gpflow.set_trainable, dgp.py:316-322).  Uses the gradient of the last dgp_grad_finish.          */
+int dgp_adam_reset(dgp_ctx* ctx);
+int dgp_adam_step(dgp_ctx* ctx, double lr, double beta_1, double beta_2, double epsilon, const uint8_t* trainable);
+/* gpflow.optimizers.NaturalGradient(gamma).minimize on the (q_mu, q_sqrt) pairs of the layers with
+ * layer_mask[l] != 0 (dgp.py:312-322,343).  Uses the gradient of the last dgp_grad_finish.         */
+int dgp_natgrad_step(dgp_ctx* ctx, double gamma, const uint8_t* layer_mask);
+
+/* ---- measurement: HIP-event timing of kernel launches on the context's stream, by category.
+ * categories: 0 = fp64-MFMA contractions over points, 1 = per-point streaming kernels,
+ *             2 = small-matrix chain (Kuu/Cholesky/KL/backward chain/natgrad), 3 = Adam.             */
+int dgp_prof_enable(dgp_ctx* ctx, int32_t on);
+int dgp_prof_read(dgp_ctx* ctx, int32_t n_cat, double* ms_out, int64_t* launches_out, double* alg_flops_out,
+                  double* alg_bytes_out);   /* synchronises, returns totals since enable, then resets */
+
+/* ---- unit-level entry points (used by tests/ to check single kernels against NumPy) ------------- */
+int dgp_dev_gemm(dgp_ctx* ctx, int32_t op /*0 NN,1 NT,2 TN*/, int64_t M, int64_t N, int64_t K, const double* A,
+                 int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha, int32_t beta,
+                 int32_t splits, int32_t tri, int64_t triblk, int32_t repeats, double* ms_per_call);
+int dgp_dev_chol(dgp_ctx* ctx, double* A, int32_t M, int32_t batch);            /* in place, lower */
+int dgp_dev_trinv(dgp_ctx* ctx, const double* L, double* X, int32_t M, int32_t batch);
+int dgp_dev_normals(dgp_ctx* ctx, uint64_t seed, int32_t layer, int32_t S, int64_t n0, int64_t N, int32_t D,
+                    double* z_out /* [S,N,D] */);
+int dgp_dev_mfma_peak(dgp_ctx* ctx, int32_t iters, double* tflops_out);          /* v_mfma_f64_16x16x4_f64 issue rate */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGP_ABI_H */

@@ -43,3 +43,34 @@ def set_oracle_state(m, g, prefix=""):
         l.kern.lengthscales = g[f"{prefix}L{i}_lengthscales"].copy()
         l.q_mu = g[f"{prefix}L{i}_q_mu"].copy()
         l.q_sqrt = g[f"{prefix}L{i}_q_sqrt"].copy()
+
+
+def product_from_golden(g, prefix="", **kw):
+    """Build the product DGP (HIP path) in the state stored in a golden fixture."""
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    dims = [g["X"].shape[1]] + list(g["num_units"])
+    kernels = [RBF(1.0, np.ones(d)) for d in dims]
+    m = DGP(g["X"], g["Y"], g["Z_init"], kernels, list(g["num_units"]), Gaussian(), white=bool(g["white"]),
+            num_samples=int(g["S"]), **kw)
+    m.likelihood.likelihood.variance.assign(g[prefix + "lik_variance"])
+    for i, l in enumerate(m.layers):
+        l.feature.Z.assign(g[f"{prefix}L{i}_Z"])
+        l.kern.variance.assign(g[f"{prefix}L{i}_variance"])
+        l.kern.lengthscales.assign(g[f"{prefix}L{i}_lengthscales"])
+        l.q_mu.assign(g[f"{prefix}L{i}_q_mu"])
+        l.q_sqrt.assign(g[f"{prefix}L{i}_q_sqrt"])
+    return m
+
+
+def split_flat(m, flat):
+    """flat vector in dgp_model_set packing -> {(layer, name): array}"""
+    out, off = {}, 0
+    names = ["Z", "variance", "lengthscales", "q_mu", "q_sqrt"]
+    for i, l in enumerate(m.layers):
+        for nm, p in zip(names, l.parameters()):
+            n = p._value.size
+            out[(i, nm)] = flat[off:off + n].reshape(p._value.shape)
+            off += n
+    out[("lik", "variance")] = flat[off]
+    return out

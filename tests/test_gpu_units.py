@@ -1,0 +1,104 @@
+"""GPU unit tests of single kernels through the C-ABI (dgp_dev_* entry points) against NumPy."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from dgp_dace import _native
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("op", ["NN", "NT", "TN"])
+@pytest.mark.parametrize("shape", [(300, 256, 64), (128, 128, 16), (1000, 48, 48), (37, 130, 50), (256, 8, 640),
+                                   (513, 3, 77), (64, 272, 272)])
+def test_gemm_matches_numpy(ctx, op, shape):
+    """MFMA operand/accumulator lane maps, LDS images, tails: asymmetric random operands."""
+    M, N, K = shape
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((K, M) if op == "TN" else (M, K))
+    B = rng.standard_normal((N, K) if op == "NT" else (K, N))
+    ref = (A.T if op == "TN" else A) @ (B.T if op == "NT" else B)
+    C = ctx.dev_gemm(op, A, B)
+    assert _rel(C, ref) < 1e-13
+    C0 = rng.standard_normal((M, N))
+    C1 = ctx.dev_gemm(op, A, B, C0=C0, alpha=0.5, beta=1)
+    assert _rel(C1, C0 + 0.5 * ref) < 1e-13
+
+
+def test_gemm_split_k_atomic_accumulation(ctx):
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((20000, 96))
+    B = rng.standard_normal((20000, 160))
+    C0 = rng.standard_normal((96, 160))
+    C = ctx.dev_gemm("TN", A, B, C0=C0, beta=1, splits=13)
+    assert _rel(C, C0 + A.T @ B) < 1e-12
+
+
+@pytest.mark.parametrize("Mp", [128, 256, 272])
+def test_gemm_triangular_hints_are_exact(ctx, Mp):
+    """TRI_* only skip structurally-zero work: results equal the dense product."""
+    rng = np.random.default_rng(Mp)
+    D, P = 3, 700
+    L = np.tril(rng.standard_normal((Mp, Mp)))
+    Kt = rng.standard_normal((P, Mp))
+    C = ctx.dev_gemm("NT", Kt, L, tri=1, triblk=Mp)                 # Kt @ L^T, L lower
+    assert _rel(C, Kt @ L.T) < 1e-13
+    C = ctx.dev_gemm("NN", Kt, L, tri=2, triblk=Mp)                 # Kt @ L
+    assert _rel(C, Kt @ L) < 1e-13
+    W = [np.tril(rng.standard_normal((Mp, Mp))) for _ in range(D)]
+    Wcat = np.concatenate(W, axis=1)                                 # [Mp, D*Mp]
+    T = ctx.dev_gemm("NN", Kt, Wcat, tri=2, triblk=Mp)
+    assert _rel(T, Kt @ Wcat) < 1e-13
+    Cb = ctx.dev_gemm("NT", T, Wcat, tri=1, triblk=Mp)               # sum_d T_d W_d^T
+    assert _rel(Cb, T @ Wcat.T) < 1e-13
+    G = ctx.dev_gemm("TN", Kt, T, tri=3, triblk=Mp, beta=1, splits=3)
+    ref = Kt.T @ T
+    for d in range(D):                                               # only the lower triangles are defined
+        blk = slice(d * Mp, (d + 1) * Mp)
+        assert _rel(np.tril(G[:, blk]), np.tril(ref[:, blk])) < 1e-12
+
+
+@pytest.mark.parametrize("M", [16, 48, 256, 512])
+def test_cholesky_and_triangular_inverse(ctx, M):
+    rng = np.random.default_rng(M)
+    B = 3
+    A = rng.standard_normal((B, M, M))
+    A = A @ A.transpose(0, 2, 1) + M * np.eye(M)[None]
+    L = ctx.dev_chol(A)
+    ref = np.linalg.cholesky(A)
+    assert _rel(L, ref) < 1e-12
+    assert np.all(np.triu(L, 1) == 0)
+    X = ctx.dev_trinv(ref)
+    assert _rel(X @ ref, np.tile(np.eye(M)[None], [B, 1, 1])) < 1e-11
+    assert np.all(np.triu(X, 1) == 0)
+
+
+def test_cholesky_reports_non_positive_definite(ctx):
+    from dgp_dace._native import NotPositiveDefinite
+    A = np.eye(32)
+    A[5, 5] = -1.0
+    with pytest.raises(NotPositiveDefinite):
+        ctx.dev_chol(A)
+
+
+def test_philox_normals_match_oracle(ctx):
+    import dgp_oracle as O
+    z = ctx.dev_normals(seed=0x1234567890ABCDEF, layer=2, S=3, n0=10 ** 10, N=257, D=5)
+    ref = O.philox_normal(0x1234567890ABCDEF, 2, 3, np.arange(10 ** 10, 10 ** 10 + 257), 5)
+    np.testing.assert_allclose(z, ref, rtol=1e-13, atol=1e-13)
+
+
+def test_fp64_mfma_issue_rate(ctx):
+    """v_mfma_f64_16x16x4_f64 micro-benchmark: the roofline denominator (spec 78.6 TFLOP/s)."""
+    t = ctx.dev_mfma_peak(20000)
+    print("fp64 MFMA issue rate: %.1f TFLOP/s" % t)
+    assert 30.0 < t < 120.0
