@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Benchmark of the DGP hot path: ELBO iterations/sec on BASELINE.json config 2
+(`num_units=[8,8]` = 3 SVGP layers, N=100k, D=8, M=256, S=10, fp64), one iteration = one
+`DGP.optimize_adam` loop body (dgp.py:271-276): ELBO forward + backward + Adam update.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+Prints ONE JSON line (rank 0).  Strong scaling: the N data points are sharded over the ranks and the
+per-point sums are all-reduced once per iteration (RCCL).  `roofline` is measured live with HIP
+events on the engine's stream (dgp_prof_*); `cpu_baseline` times the oracle's torch-CPU restatement
+of the reference's dense formulation on a bounded sample, on rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "dgp-toolbox_amd"))
+
+import numpy as np  # noqa: E402
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # AMD MI355X fp64 matrix spec; issue-rate microbench in DESIGN.md
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic(N, D, M, seed=0):
+    """BASELINE.md §3 inputs."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, (N, D))
+    w = rng.standard_normal((D, 1))
+    Y = np.sin(2 * np.pi * X @ w / np.sqrt(D)) + (X[:, :1] > 0.5) + 0.05 * rng.standard_normal((N, 1))
+    X = (X - X.mean(0)) / X.std(0)
+    Y = (Y - Y.mean(0)) / Y.std(0)
+    Z = X[rng.permutation(N)[:M]].copy()
+    return X, Y, Z
+
+
+def alg_flops_step(N, S, dims, M, Dy):
+    """Algorithmic flops of one iteration as built (triangular products, first layer once per data point):
+    per layer and point (1 + D_out) * M(M+1) forward, twice that backward."""
+    total = 0.0
+    douts = dims[1:] + [Dy]
+    for l, dout in enumerate(douts):
+        P = N if l == 0 else N * S
+        total += 3.0 * P * (1 + dout) * M * (M + 1.0)
+    return total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--N", type=int, default=100_000)
+    ap.add_argument("--D", type=int, default=8)
+    ap.add_argument("--M", type=int, default=256)
+    ap.add_argument("--S", type=int, default=10)
+    ap.add_argument("--num-units", type=str, default="8,8")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8192)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+
+    num_units = [int(x) for x in args.num_units.split(",") if x]
+    dims = [args.D] + num_units
+    X, Y, Z = synthetic(args.N, args.D, args.M)
+    stdout = sys.stdout
+    sys.stdout = open(os.devnull, "w")          # the constructor prints the architecture (as the reference does)
+    model = DGP(X, Y, Z, [RBF(variance=1.0, lengthscales=[1.0] * d) for d in dims], num_units, Gaussian(),
+                num_samples=args.S, seed=0, device=local_rank)
+    sys.stdout = stdout
+    for layer in model.layers[:-1]:
+        layer.q_sqrt.assign(layer.q_sqrt * 1e-3)      # dgp.py:268-269, what optimize_adam does first
+    ctx = model._sync_model()
+    ctx.adam_reset()
+    flags = model._trainable_flags()
+
+    def step():
+        c = model._grad_step(model.data)
+        c.adam_step(0.01, 0.9, 0.999, 1e-7, flags)
+
+    def fence():
+        ctx.sync()
+        if dist:
+            dist.barrier()
+            ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ctx.prof_read()
+    ctx.prof_enable(False)
+    model._device_newer = True
+    if dist:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    elbo_last = ctx.last_elbo()
+
+    if rank == 0:
+        it_s = args.steps / dt
+        mf = prof["mfma_contractions"]
+        achieved = mf["alg_flops"] / (mf["ms"] * 1e-3) / 1e12 if mf["ms"] > 0 else 0.0
+        name, cus, mem = ctx.device_info()
+        out = {
+            "metric": "ELBO iterations/sec (2-layer DGP, N=100k, M=256) at 1/2/4/8 GPUs; fp64 ELBO match",
+            "value": it_s, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"DGP num_units={num_units} ({len(num_units) + 1} SVGP layers), N={args.N}, "
+                                   f"D={args.D}, M={args.M}, S={args.S}, full batch, optimize_adam iteration",
+                       "N": args.N, "D": args.D, "M": args.M, "S": args.S, "num_units": num_units,
+                       "parallelism": f"data points sharded over {world} GPU(s), one all-reduce per iteration"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "dgp::gemm_f64_kernel (all point contractions, rank 0)",
+                         "kernel_ms_per_step": mf["ms"] / args.steps, "launches_per_step": mf["launches"] / args.steps,
+                         "alg_flops_per_step_rank0": mf["alg_flops"] / args.steps,
+                         "whole_step_frac": alg_flops_step(args.N, args.S, dims, args.M, 1) / world / (dt / args.steps)
+                                            / 1e12 / FP64_MFMA_PEAK_TFLOPS},
+            "breakdown_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+            "elbo_last": elbo_last, "device": name,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, num_units, X, Y, Z)
+            out["elbo_rel_err_vs_oracle"] = out["cpu_baseline"].pop("elbo_rel_err")
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, num_units, X, Y, Z):
+    """Oracle (torch-CPU fp64 restatement of the reference's dense formulation, autograd backward) timed on
+    the first `cpu_sample` data points, all host cores; rate extrapolated linearly in N.  Also checks the
+    GPU ELBO against the oracle on that sample with identical Philox normals."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import dgp_oracle as O
+    import dgp_oracle_torch as T
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = min(args.cpu_sample, args.N)
+    dims = [args.D] + num_units
+    Xs, Ys = X[:n].copy(), Y[:n].copy()
+    mo = O.OracleDGP(Xs, Ys, Z, [O.RBF(1.0, np.ones(d)) for d in dims], num_units, num_samples=args.S)
+    for l in mo.layers[:-1]:
+        l.q_sqrt = l.q_sqrt * 1e-3
+    zs = O.draw_zs(mo, 123, args.S, n)
+    T.elbo_and_grads(mo, [z[:, :256] for z in zs], data=(Xs[:256], Ys[:256]), chunk=256)   # warm-up
+    t0 = time.perf_counter()
+    elbo_o, _ = T.elbo_and_grads(mo, zs, chunk=256)
+    t = time.perf_counter() - t0
+    stdout = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+    mg = DGP(Xs, Ys, Z, [RBF(1.0, [1.0] * d) for d in dims], num_units, Gaussian(), num_samples=args.S)
+    sys.stdout = stdout
+    for l in mg.layers[:-1]:
+        l.q_sqrt.assign(l.q_sqrt * 1e-3)
+    c = mg._sync_model()
+    mg._sync_data(mg.data)
+    Ld, KL = c.elbo(args.S, 123, None)
+    rel = abs((Ld - KL) - elbo_o) / abs(elbo_o)
+    return {"value": 1.0 / (t * args.N / n), "unit": "it/s", "cores": cores, "kind": "port",
+            "sample": f"{n} of {args.N} data points (S={args.S}), 1 timed ELBO+autograd evaluation = {t:.2f} s, "
+                      f"extrapolated linearly in N; torch-CPU fp64, dense SK@A formulation of layers.py:243-276",
+            "elbo_rel_err": rel}
+
+
+if __name__ == "__main__":
+    main()
