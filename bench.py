@@ -26,6 +26,22 @@ FP64_MFMA_PEAK_TFLOPS = 78.6     # AMD MI355X fp64 matrix spec;
 HBM_PEAK_GBS = 8000.0
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """CPU share of this process: affinity mask and cgroup quota (os.cpu_count() reports the whole host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def synthetic(N, D, M, seed=0):
     """BASELINE.md §3 inputs."""
     rng = np.random.default_rng(seed)
@@ -86,6 +102,7 @@ def main():
     sys.stdout = stdout
     for layer in model.layers[:-1]:
         layer.q_sqrt.assign(layer.q_sqrt * 1e-3)      # dgp.py:268-269, what optimize_adam does first
+    log("model built")
     ctx = model._sync_model()
     ctx.adam_reset()
     flags = model._trainable_flags()
@@ -103,12 +120,14 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    log("warm-up done")
     ctx.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    log(f"timed region done: {dt:.3f} s")
     prof = ctx.prof_read()
     ctx.prof_enable(False)
     model._device_newer = True
@@ -162,7 +181,8 @@ def cpu_baseline(args, num_units, X, Y, Z):
     import dgp_oracle_torch as T
     from dgp_dace.gpflow_compat import RBF, Gaussian
     from dgp_dace.models.dgp import DGP
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
+    log(f"cpu_baseline: {cores} cores")
     torch.set_num_threads(cores)
     n = min(args.cpu_sample, args.N)
     dims = [args.D] + num_units
@@ -175,6 +195,7 @@ def cpu_baseline(args, num_units, X, Y, Z):
     t0 = time.perf_counter()
     elbo_o, _ = T.elbo_and_grads(mo, zs, chunk=256)
     t = time.perf_counter() - t0
+    log(f"cpu_baseline: timed evaluation {t:.2f} s")
     stdout = sys.stdout
     sys.stdout = open(os.devnull, "w")
     mg = DGP(Xs, Ys, Z, [RBF(1.0, [1.0] * d) for d in dims], num_units, Gaussian(), num_samples=args.S)

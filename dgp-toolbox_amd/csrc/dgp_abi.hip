@@ -175,7 +175,7 @@ int G(dgp_ctx* ctx, int cat, GemmOp op, long M, long N, long K, const double* A,
 }
 
 int pick_splits(long Mrows, long Ncols, long K) {
-  const long tiles = ((Mrows + 127) / 128) * ((Ncols + 127) / 128);
+  const long tiles = ((Mrows + 127) / 128) * ((Ncols + 63) / 64);
   long s = 1536 / (tiles > 0 ? tiles : 1);
   const long kmax = K / 512;
   if (s > kmax) s = kmax;
@@ -304,8 +304,7 @@ int prep(dgp_ctx* ctx) {
     HIPCHK(pack_q(ctx->st, P(ctx, y.off_qsqrt), P(ctx, y.off_qmu), M, Mp, D, y.Lq, y.qmu_p));
     HIPCHK(rbf_kuu(ctx->st, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din, y.Kuu));
     HIPCHK(copy_mat(ctx->st, y.Kuu, y.Lu, MM));
-    HIPCHK(chol_lower(ctx->st, y.Lu, Mp, 1, ctx->info));
-    HIPCHK(trinv_lower(ctx->st, y.Lu, y.Linv, Mp, 1));
+    HIPCHK(potrf_inv(ctx->st, y.Lu, y.Linv, ctx->sm[9], Mp, 1, ctx->info));
     if (y.d.white) {
       HIPCHK(lq_to_wcat(ctx->st, y.Lq, Mp, D, y.Wcat));
       HIPCHK(copy_mat(ctx->st, y.qmu_p, y.u, (long)Mp * D));
@@ -816,19 +815,18 @@ int dgp_natgrad_step(dgp_ctx* ctx, double gamma, const uint8_t* layer_mask) {
     double *Li = ctx->sm[0], *T = ctx->sm[1], *T1 = ctx->sm[2], *Gm = ctx->sm[3], *Pinv = ctx->sm[4], *Pn = ctx->sm[5],
            *Ri = ctx->sm[6], *Sn = ctx->sm[7];
     ProfScope ps(ctx, 2, 0, 0);
-    HIPCHK(trinv_lower(ctx->st, y.Lq, Li, Mp, D));
+    HIPCHK(trinv_lower(ctx->st, y.Lq, Li, ctx->sm[9], Mp, D));
     RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Lq, Mp, y.dLq, Mp, T, Mp, 1.0, 0, D, MM, MM, MM));
     HIPCHK(phi_tril_halfdiag(ctx->st, T, Mp, D));
     RET(G(ctx, 2, GEMM_NN, Mp, Mp, Mp, T, Mp, Li, Mp, T1, Mp, 1.0, 0, D, MM, MM, MM));
     RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, Li, Mp, T1, Mp, Gm, Mp, 1.0, 0, D, MM, MM, MM));       // d ELBO / d Sigma (unsym.)
     RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, Li, Mp, Li, Mp, Pinv, Mp, 1.0, 0, D, MM, MM, MM));     // Sigma^-1
     HIPCHK(symmetrize_axpy(ctx->st, Gm, Pinv, -2.0 * gamma, Pn, Mp, D));                       // loss = -ELBO
-    HIPCHK(chol_lower(ctx->st, Pn, Mp, D, ctx->info));
-    HIPCHK(trinv_lower(ctx->st, Pn, Ri, Mp, D));
+    HIPCHK(potrf_inv(ctx->st, Pn, Ri, ctx->sm[9], Mp, D, ctx->info));
     RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, Ri, Mp, Ri, Mp, Sn, Mp, 1.0, 0, D, MM, MM, MM));       // Sigma'
     HIPCHK(natgrad_mu(ctx->st, Sn, y.dqmu_p, gamma, y.qmu_p, M, Mp, D));
     HIPCHK(copy_mat(ctx->st, Sn, y.Lq, MM * D));
-    HIPCHK(chol_lower(ctx->st, y.Lq, Mp, D, ctx->info));
+    HIPCHK(potrf_inv(ctx->st, y.Lq, ctx->sm[8], ctx->sm[9], Mp, D, ctx->info));
     HIPCHK(store_q(ctx->st, y.Lq, y.qmu_p, M, Mp, D, ctx->params + y.off_qsqrt, ctx->params + y.off_qmu));
   }
   return DGP_OK;
@@ -901,23 +899,27 @@ int dgp_dev_chol(dgp_ctx* ctx, double* A, int32_t M, int32_t batch) {
   const size_t n = (size_t)batch * M * M;
   RET(dev_alloc(ctx, &d, n));
   HIPCHK(hipMemcpy(d, A, n * 8, hipMemcpyHostToDevice));
-  HIPCHK(chol_lower(ctx->st, d, M, batch, ctx->info));
+  double *x, *t;
+  RET(dev_alloc(ctx, &x, n)); RET(dev_alloc(ctx, &t, n));
+  HIPCHK(potrf_inv(ctx->st, d, x, t, M, batch, ctx->info));
   HIPCHK(hipStreamSynchronize(ctx->st));
   HIPCHK(hipMemcpy(A, d, n * 8, hipMemcpyDeviceToHost));
-  dev_free(d);
+  dev_free(d); dev_free(x); dev_free(t);
   return check_flags(ctx);
 }
 
 int dgp_dev_trinv(dgp_ctx* ctx, const double* L, double* X, int32_t M, int32_t batch) {
   if (!ctx || !L || !X || M <= 0 || batch <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_dev_trinv: bad arguments");
-  double *dl, *dx;
+  if (M % 16 != 0) return fail(ctx, DGP_ERR_INVALID, "dgp_dev_trinv: M must be a multiple of 16");
+  double *dl, *dx, *dt;
   const size_t n = (size_t)batch * M * M;
-  RET(dev_alloc(ctx, &dl, n)); RET(dev_alloc(ctx, &dx, n));
+  RET(dev_alloc(ctx, &dl, n)); RET(dev_alloc(ctx, &dx, n)); RET(dev_alloc(ctx, &dt, n));
   HIPCHK(hipMemcpy(dl, L, n * 8, hipMemcpyHostToDevice));
-  HIPCHK(trinv_lower(ctx->st, dl, dx, M, batch));
+  HIPCHK(hipMemset(dx, 0, n * 8));
+  HIPCHK(trinv_lower(ctx->st, dl, dx, dt, M, batch));
   HIPCHK(hipStreamSynchronize(ctx->st));
   HIPCHK(hipMemcpy(X, dx, n * 8, hipMemcpyDeviceToHost));
-  dev_free(dl); dev_free(dx);
+  dev_free(dl); dev_free(dx); dev_free(dt);
   return DGP_OK;
 }
 

@@ -1,4 +1,4 @@
-// fp64 MFMA GEMM engine for gfx950 (v_mfma_f64_16x16x4_f64), LDS-staged, 4 waves / workgroup.
+// fp64 MFMA GEMM engine for gfx950 (v_mfma_f64_4x4x4_4b_f64), LDS-staged, 4 waves / workgroup.
 //
 // Every dense contraction of the SVGP-layer path runs through this one kernel family:
 //   forward   Ct  = Kt  * Linv^T        (reference: tf.linalg.triangular_solve, layers.py:245-247)
@@ -17,9 +17,11 @@
 // image a pitch of BM+16 / BN+16 doubles (MI355X_MICROARCH.md §LDS: ds_read_b64 is serviced in two
 // 32-lane groups over 64 four-byte banks).
 //
-// MFMA operand maps for v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md §3): lane l holds
-// A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; the 4 results per lane are
-// D[row = (l>>4) + 4*r][col = l&15], r = 0..3.
+// Matrix instruction: v_mfma_f64_4x4x4_4b_f64 issues at 16-18 cycles (72-74 TFLOP/s chip-wide, 94 % of
+// the 78.6 TFLOP/s fp64 spec) while v_mfma_f64_16x16x4_f64 sustains only ~100 cycles per instruction
+// (47 TFLOP/s) on gfx950 — measured by tools/mfma_bench.hip.  Lane maps, probed by tools/mfma_probe.hip:
+// lane l supplies A[c = l&15][k = l>>4] and B[k = l>>4][c = l&15] (the 16x16x4 operand layout) and
+// receives D[4*(c>>2) + (l>>4)][c], i.e. only the four diagonal 4x4 blocks of the 16x16 product.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -149,7 +151,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   const long ktiles_per_blk = (khi - klo + BK - 1) / BK;
   const long ktiles = ktiles_per_blk * nkb;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it scalar
   const int wr = wave / WC, wc = wave % WC;
   const int li = lane & 15, lk = lane >> 4;
 
@@ -193,45 +196,67 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   }
   __syncthreads();
 
+  // Main loop: one straight-line MFMA path.  The triangular structure is exploited at tile level only
+  // (k-range per 128x64 tile, tiles above the diagonal skipped): in-loop predication made hipcc move the
+  // accumulators between VGPRs and AGPRs around every MFMA (measured 2.3x slower).
   for (long kt = 0; kt < ktiles; ++kt) {
     const int cur = (int)(kt & 1);
     const bool more = (kt + 1 < ktiles);
+#ifndef DGP_ABLATE_GLOBAL
     if (more) gload(kt + 1);                       // next tile's global loads fly under the MFMAs
+#endif
     const double* as = smem + cur * (Cfg::AS_SZ + Cfg::BS_SZ);
     const double* bs = as + Cfg::AS_SZ;
 #pragma unroll
     for (int k4 = 0; k4 < BK / 4; ++k4) {
-      double fa[FM], fb[FN];
+#ifdef DGP_ABLATE_LDSREAD
+      const int kk = lk;
+#else
+      const int kk = k4 * 4 + lk;
+#endif
+      double fa[FM], fb[FN][4];
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const int row = wr * Cfg::WM + i * 16 + li, kk = k4 * 4 + lk;
+        const int row = (i * WR + wr) * 16 + li;
         fa[i] = TA ? as[kk * Cfg::LDA_S + row] : as[row * Cfg::LDA_S + kk];
       }
+      // v_mfma_f64_4x4x4_4b computes the four diagonal 4x4 blocks of (A frag) x (B frag); rotating the
+      // B fragment's columns by 4r inside its 16-column block yields the r-th block diagonal.
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int col = wc * Cfg::WN + j * 16 + li, kk = k4 * 4 + lk;
-        fb[j] = TB ? bs[col * Cfg::LDB_S + kk] : bs[kk * Cfg::LDB_S + col];
-      }
+      for (int j = 0; j < FN; ++j)
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+        for (int r = 0; r < 4; ++r) {
+          const int col = (j * WC + wc) * 16 + ((li + 4 * r) & 15);
+          fb[j][r] = TB ? bs[col * Cfg::LDB_S + kk] : bs[kk * Cfg::LDB_S + col];
+        }
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#ifdef DGP_ABLATE_MFMA
+            acc[i][j][r] += fa[i] + fb[j][r];
+#else
+            acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[i], fb[j][r], acc[i][j][r], 0, 0, 0);
+#endif
     }
+#ifndef DGP_ABLATE_GLOBAL
     if (more) sstore(cur ^ 1);
+#endif
     __syncthreads();
   }
 
-  // ---- epilogue ----
+  // ---- epilogue: acc[i][j][r] of lane l is C[rowblk*16 + 4*((l&15)>>2) + (l>>4)][colblk*16 + ((l&15) + 4r) & 15]
   const bool atomic = g.splits > 1;
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      const long col = n0 + wc * Cfg::WN + j * 16 + li;
+      const long row = m0 + (long)(i * WR + wr) * 16 + 4 * (li >> 2) + lk;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long row = m0 + wr * Cfg::WM + i * 16 + lk + 4 * r;
+        const long col = n0 + (long)(j * WC + wc) * 16 + ((li + 4 * r) & 15);
         if (row < g.M && col < g.N) {
           double* p = C + row * g.ldc + col;
           const double v = g.alpha * acc[i][j][r];

@@ -24,8 +24,8 @@ static hipError_t dispatch(hipStream_t st, const GemmArgs& a) {
   const bool vb = vec2_ok(a.B, a.ldb, TB ? a.K : a.N, a.sB, a.batch);
   const bool skinny = a.N <= 16;
   if (!skinny) {
-    if (va && vb) return launch<TA, TB, 128, 128, 16, 2, 2, 2, 2>(st, a);
-    return launch<TA, TB, 128, 128, 16, 2, 2, 1, 1>(st, a);
+    if (va && vb) return launch<TA, TB, 128, 64, 16, 2, 2, 2, 2>(st, a);
+    return launch<TA, TB, 128, 64, 16, 2, 2, 1, 1>(st, a);
   }
   if (va) return launch<TA, TB, 128, 16, 16, 4, 1, 2, 1>(st, a);
   return launch<TA, TB, 128, 16, 16, 4, 1, 1, 1>(st, a);

@@ -35,110 +35,126 @@ hipError_t rbf_kuu(hipStream_t st, const double* Z, const double* var, const dou
   LAUNCH_CHECK();
 }
 
-// ---------------------------------------------------------------------------------------- Cholesky
-// Right-looking blocked Cholesky, one 1024-thread workgroup per matrix; the diagonal block is
-// factored in LDS, the panel solve keeps one row per thread in registers, the trailing update reads
-// the panel rows from global memory (L2-resident: M*M*8 B <= 8 MiB).
-constexpr int CH_NB = 32;
+// ---------------------------------------------------------------------------------------- Cholesky + L^-1
+// Recursive blocked factorisation driven from the host, all O(n^3) work in the MFMA GEMM engine:
+//   A = [A11 . ; A21 A22]:  (L11, X11) = potrf_inv(A11);  L21 = A21 X11^T;  A22 -= L21 L21^T;
+//   (L22, X22) = potrf_inv(A22);  X21 = -X22 (L21 X11)
+// Leaves (n <= 64) are factored and inverted in LDS by one workgroup.  Replaces tf.linalg.cholesky /
+// triangular_solve on Kuu (layers.py:231,245-247) and GPflow's chol(-2 nat2), its inverse and chol(S).
+constexpr int LEAF = 64;
 
-__global__ __launch_bounds__(1024) void chol_kernel(double* __restrict__ Aall, int Mp, int* __restrict__ info) {
-  double* A = Aall + (long)blockIdx.x * Mp * Mp;
-  __shared__ double Dg[CH_NB][CH_NB + 1];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int j0 = 0; j0 < Mp; j0 += CH_NB) {
-    const int nb = min(CH_NB, Mp - j0);
-    for (int idx = tid; idx < nb * nb; idx += nt) {
-      const int r = idx / nb, c = idx % nb;
-      Dg[r][c] = A[(long)(j0 + r) * Mp + j0 + c];
-    }
-    __syncthreads();
-    for (int c = 0; c < nb; ++c) {
+__global__ __launch_bounds__(256) void leaf_potrf_inv_kernel(double* __restrict__ Aall, double* __restrict__ Xall, int ld,
+                                                             long stride, int off, int n, int do_chol,
+                                                             int* __restrict__ info) {
+  __shared__ double Ls[LEAF][LEAF + 1];
+  __shared__ double Xs[LEAF][LEAF + 1];
+  double* A = Aall + (long)blockIdx.x * stride + (long)off * ld + off;
+  double* X = Xall + (long)blockIdx.x * stride + (long)off * ld + off;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < n * n; idx += 256) {
+    const int r = idx / n, c = idx % n;
+    Ls[r][c] = (c <= r) ? A[(long)r * ld + c] : 0.0;
+  }
+  __syncthreads();
+  if (do_chol) {
+    for (int c = 0; c < n; ++c) {
       if (tid == 0) {
-        const double d = Dg[c][c];
-        if (!(d > 0.0)) { atomicOr(info, 1); Dg[c][c] = nan(""); }
-        else Dg[c][c] = sqrt(d);
+        const double d = Ls[c][c];
+        if (!(d > 0.0)) { atomicOr(info, 1); Ls[c][c] = nan(""); }
+        else Ls[c][c] = sqrt(d);
       }
       __syncthreads();
-      if (tid > c && tid < nb) Dg[tid][c] /= Dg[c][c];
+      if (tid > c && tid < n) Ls[tid][c] /= Ls[c][c];
       __syncthreads();
-      for (int idx = tid; idx < nb * nb; idx += nt) {
-        const int i = idx / nb, k = idx % nb;
-        if (k > c && i >= k) Dg[i][k] -= Dg[i][c] * Dg[k][c];
+      for (int idx = tid; idx < n * n; idx += 256) {
+        const int i = idx / n, k = idx % n;
+        if (k > c && i >= k) Ls[i][k] -= Ls[i][c] * Ls[k][c];
       }
       __syncthreads();
     }
-    for (int idx = tid; idx < nb * nb; idx += nt) {
-      const int r = idx / nb, c = idx % nb;
-      A[(long)(j0 + r) * Mp + j0 + c] = (c <= r) ? Dg[r][c] : 0.0;
-    }
-    // panel: rows below the diagonal block,  X = A21 * L11^-T
-    const int T = Mp - j0 - nb;
-    for (int r = tid; r < T; r += nt) {
-      double* row = A + (long)(j0 + nb + r) * Mp + j0;
-      double x[CH_NB];
-#pragma unroll
-      for (int c = 0; c < CH_NB; ++c) x[c] = (c < nb) ? row[c] : 0.0;
-#pragma unroll
-      for (int c = 0; c < CH_NB; ++c) {
-        if (c < nb) {
-          double s = x[c];
-#pragma unroll
-          for (int t = 0; t < CH_NB; ++t)
-            if (t < c) s -= x[t] * Dg[c][t];
-          x[c] = s / Dg[c][c];
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < CH_NB; ++c)
-        if (c < nb) row[c] = x[c];
-    }
-    // zero the strictly-upper part right of the diagonal block (clean lower-triangular output)
-    for (long idx = tid; idx < (long)nb * T; idx += nt) {
-      const int r = (int)(idx / T), c = (int)(idx % T);
-      A[(long)(j0 + r) * Mp + j0 + nb + c] = 0.0;
-    }
-    __syncthreads();
-    // trailing update  A22 -= X X^T  (lower part)
-    for (long idx = tid; idx < (long)T * T; idx += nt) {
-      const int i = (int)(idx / T), k = (int)(idx % T);
-      if (k <= i) {
-        const double* ri = A + (long)(j0 + nb + i) * Mp + j0;
-        const double* rk = A + (long)(j0 + nb + k) * Mp + j0;
-        double s = 0.0;
-        for (int c = 0; c < nb; ++c) s += ri[c] * rk[c];
-        A[(long)(j0 + nb + i) * Mp + j0 + nb + k] -= s;
-      }
-    }
-    __syncthreads();
   }
-}
-
-hipError_t chol_lower(hipStream_t st, double* A, int Mp, int batch, int* info) {
-  hipLaunchKernelGGL(chol_kernel, dim3(batch), dim3(1024), 0, st, A, Mp, info);
-  LAUNCH_CHECK();
-}
-
-// ---------------------------------------------------------------------------------------- L^-1
-// Column-parallel forward substitution: thread j owns column j of X = L^-1.
-__global__ __launch_bounds__(1024) void trinv_kernel(const double* __restrict__ Lall, double* __restrict__ Xall,
-                                                     int Mp) {
-  const double* L = Lall + (long)blockIdx.x * Mp * Mp;
-  double* X = Xall + (long)blockIdx.x * Mp * Mp;
-  for (int j = threadIdx.x; j < Mp; j += blockDim.x) {
-    for (int i = 0; i < j; ++i) X[(long)i * Mp + j] = 0.0;
-    X[(long)j * Mp + j] = 1.0 / L[(long)j * Mp + j];
-    for (int i = j + 1; i < Mp; ++i) {
-      const double* Li = L + (long)i * Mp;
+  // inverse: thread j owns column j (forward substitution, everything in LDS)
+  if (tid < n) {
+    const int j = tid;
+    for (int i = 0; i < j; ++i) Xs[i][j] = 0.0;
+    Xs[j][j] = 1.0 / Ls[j][j];
+    for (int i = j + 1; i < n; ++i) {
       double s = 0.0;
-      for (int k = j; k < i; ++k) s += Li[k] * X[(long)k * Mp + j];
-      X[(long)i * Mp + j] = -s / Li[i];
+      for (int k = j; k < i; ++k) s += Ls[i][k] * Xs[k][j];
+      Xs[i][j] = -s / Ls[i][i];
     }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n * n; idx += 256) {
+    const int r = idx / n, c = idx % n;
+    if (do_chol) A[(long)r * ld + c] = Ls[r][c];
+    X[(long)r * ld + c] = Xs[r][c];
   }
 }
 
-hipError_t trinv_lower(hipStream_t st, const double* L, double* X, int Mp, int batch) {
-  hipLaunchKernelGGL(trinv_kernel, dim3(batch), dim3(Mp < 1024 ? ((Mp + 63) / 64) * 64 : 1024), 0, st, L, X, Mp);
-  LAUNCH_CHECK();
+__global__ void zero_block_kernel(double* __restrict__ Aall, int ld, long stride, int r0, int c0, int nr, int nc) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)nr * nc) return;
+  double* A = Aall + (long)blockIdx.y * stride;
+  A[(long)(r0 + idx / nc) * ld + c0 + idx % nc] = 0.0;
+}
+
+static hipError_t sub_gemm(hipStream_t st, GemmOp op, long M, long N, long K, const double* A, const double* B, double* C,
+                           int ld, long stride, int batch, double alpha, int beta, long sA = -1, long sB = -1) {
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.lda = g.ldb = g.ldc = ld; g.M = M; g.N = N; g.K = K;
+  g.sA = sA < 0 ? stride : sA; g.sB = sB < 0 ? stride : sB; g.sC = stride;
+  g.batch = batch; g.splits = 1; g.ksplit = 0; g.alpha = alpha; g.beta = beta; g.tri = TRI_NONE; g.triblk = 0;
+  return gemm_f64(st, op, g);
+}
+
+// A (lower part used; overwritten by L, upper zeroed), X = L^-1; tmp: scratch of the same shape as A
+static hipError_t potrf_inv_rec(hipStream_t st, double* A, double* X, double* tmp, int ld, long stride, int batch, int off,
+                                int n, int do_chol, int* info) {
+  hipError_t e;
+  if (n <= LEAF) {
+    hipLaunchKernelGGL(leaf_potrf_inv_kernel, dim3(batch), dim3(256), 0, st, A, X, ld, stride, off, n, do_chol, info);
+    return hipGetLastError();
+  }
+  int n1 = ((n / 2 + 15) / 16) * 16;
+  if (n1 > n - 16) n1 = n - 16;
+  const int n2 = n - n1;
+  double* A11 = A + (long)off * ld + off;           (void)A11;
+  double* A21 = A + (long)(off + n1) * ld + off;
+  double* A22 = A + (long)(off + n1) * ld + off + n1;
+  double* X11 = X + (long)off * ld + off;
+  double* X21 = X + (long)(off + n1) * ld + off;
+  double* X22 = X + (long)(off + n1) * ld + off + n1;
+  double* T = tmp + (long)(off + n1) * ld + off;    // [n2 x n1] scratch at the same position
+  if ((e = potrf_inv_rec(st, A, X, tmp, ld, stride, batch, off, n1, do_chol, info)) != hipSuccess) return e;
+  if (do_chol) {
+    // L21 = A21 X11^T   (into T, then copy back into A21 by a second product-free pass: write directly)
+    if ((e = sub_gemm(st, GEMM_NT, n2, n1, n1, A21, X11, T, ld, stride, batch, 1.0, 0)) != hipSuccess) return e;
+    // A22 -= L21 L21^T
+    if ((e = sub_gemm(st, GEMM_NT, n2, n2, n1, T, T, A22, ld, stride, batch, -1.0, 1)) != hipSuccess) return e;
+    // A21 <- L21 : copy T -> A21 as  A21 = T * I  is wasteful; use a strided 2D copy per batch
+    for (int b = 0; b < batch; ++b)
+      if ((e = hipMemcpy2DAsync(A21 + (long)b * stride, (size_t)ld * 8, T + (long)b * stride, (size_t)ld * 8, (size_t)n1 * 8, n2,
+                                hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+  }
+  if ((e = potrf_inv_rec(st, A, X, tmp, ld, stride, batch, off + n1, n2, do_chol, info)) != hipSuccess) return e;
+  // X21 = -X22 (L21 X11)
+  if ((e = sub_gemm(st, GEMM_NN, n2, n1, n1, A21, X11, T, ld, stride, batch, 1.0, 0)) != hipSuccess) return e;
+  if ((e = sub_gemm(st, GEMM_NN, n2, n1, n2, X22, T, X21, ld, stride, batch, -1.0, 0)) != hipSuccess) return e;
+  // clean upper-right blocks (structural zeros are relied upon by the triangular hints of the GEMMs)
+  const long nz = (long)n1 * n2;
+  if (do_chol)
+    hipLaunchKernelGGL(zero_block_kernel, dim3((unsigned)((nz + 255) / 256), batch), dim3(256), 0, st, A, ld, stride, off, off + n1, n1, n2);
+  hipLaunchKernelGGL(zero_block_kernel, dim3((unsigned)((nz + 255) / 256), batch), dim3(256), 0, st, X, ld, stride, off, off + n1, n1, n2);
+  return hipGetLastError();
+}
+
+hipError_t potrf_inv(hipStream_t st, double* A, double* X, double* tmp, int Mp, int batch, int* info) {
+  return potrf_inv_rec(st, A, X, tmp, Mp, (long)Mp * Mp, batch, 0, Mp, 1, info);
+}
+
+hipError_t trinv_lower(hipStream_t st, const double* L, double* X, double* tmp, int Mp, int batch) {
+  return potrf_inv_rec(st, const_cast<double*>(L), X, tmp, Mp, (long)Mp * Mp, batch, 0, Mp, 0, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------- packing

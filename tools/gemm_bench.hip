@@ -1,0 +1,61 @@
+// Standalone tuning harness for the fp64 MFMA GEMM engine (includes the kernel template directly).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I dgp-toolbox_amd/csrc tools/gemm_bench.hip -o tools/gemm_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "gemm_f64.h"
+using namespace dgp;
+
+template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC>
+double run(const char* name, long M, long N, long K, int splits, int tri, long triblk, double* dA, double* dB, double* dC,
+           long lda, long ldb, long ldc, double work_frac) {
+  GemmArgs a;
+  a.A = dA; a.B = dB; a.C = dC; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  a.sA = a.sB = a.sC = 0; a.batch = 1; a.splits = splits; a.alpha = 1.0; a.beta = splits > 1 ? 1 : 0; a.tri = tri; a.triblk = triblk;
+  long per = (K + splits - 1) / splits; per = ((per + BK - 1) / BK) * BK; a.ksplit = per; a.splits = (int)((K + per - 1) / per);
+  const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  dim3 grid((unsigned)tiles, (unsigned)a.splits);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, 2, 2>), grid, dim3(256), 0, 0, a);
+  hipDeviceSynchronize();
+  const int reps = 5;
+  hipEventRecord(e0);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, 2, 2>), grid, dim3(256), 0, 0, a);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+  const double dense = 2.0 * M * N * K;
+  printf("%-44s %4dx%3dx%2d w%dx%d  %8.3f ms  dense-equiv %6.1f TF  executed(~%.0f%%) %6.1f TF\n", name, BM, BN, BK, WR, WC, ms,
+         dense / ms / 1e9, work_frac * 100, dense * work_frac / ms / 1e9);
+  return ms;
+}
+
+int main(int argc, char** argv) {
+  const long P = argc > 1 ? atol(argv[1]) : 200000, Mp = 256, D = 8;
+  const long DM = D * Mp;
+  double *A, *B, *C;
+  hipMalloc(&A, P * DM * 8); hipMalloc(&B, (size_t)Mp * DM * 8 + P * Mp * 8); hipMalloc(&C, P * DM * 8);
+  std::vector<double> h(1 << 20);
+  for (auto& x : h) x = (double)rand() / RAND_MAX - 0.5;
+  for (size_t off = 0; off < (size_t)P * DM; off += h.size()) hipMemcpy(A + off, h.data(), std::min(h.size(), (size_t)P * DM - off) * 8, hipMemcpyHostToDevice);
+  for (size_t off = 0; off < (size_t)Mp * DM + P * Mp; off += h.size()) hipMemcpy(B + off, h.data(), std::min(h.size(), (size_t)Mp * DM + P * Mp - off) * 8, hipMemcpyHostToDevice);
+  printf("P=%ld Mp=%ld D=%ld\n", P, Mp, D);
+#define NN_DENSE(BM, BN, BK, WR, WC) run<false, false, BM, BN, BK, WR, WC>("NN  Tt=Ct*Wcat dense", P, DM, Mp, 1, 0, 0, A, B, C, Mp, DM, DM, 1.0)
+#define NN_TRI(BM, BN, BK, WR, WC) run<false, false, BM, BN, BK, WR, WC>("NN  Tt=Ct*Wcat tri", P, DM, Mp, 1, TRI_B_LOWER, Mp, A, B, C, Mp, DM, DM, 0.5 + 0.5 * BN / Mp)
+#define NT_TRI(BM, BN, BK, WR, WC) run<false, true, BM, BN, BK, WR, WC>("NT  Cbar=sTt*Wcat^T tri (K=D*Mp)", P, Mp, DM, 1, TRI_B_UPPER, Mp, A, B, C, DM, DM, Mp, 0.5 + 0.5 * BN / Mp)
+#define TN_GRAM(BM, BN, BK, WR, WC) run<true, false, BM, BN, BK, WR, WC>("TN  dW=Ct^T*sTt (K=P) splits", Mp, DM, P, 48, TRI_OUT_LOWER, Mp, B + Mp * DM, A, C, Mp, DM, DM, 0.75)
+  NN_DENSE(128, 64, 16, 2, 2);
+  NN_DENSE(128, 128, 16, 2, 2);
+  NN_DENSE(256, 64, 16, 4, 1);
+  NN_DENSE(128, 64, 32, 2, 2);
+  NN_DENSE(64, 64, 16, 2, 2);
+  NN_TRI(128, 64, 16, 2, 2);
+  NN_TRI(128, 128, 16, 2, 2);
+  NT_TRI(128, 64, 16, 2, 2);
+  NT_TRI(128, 128, 16, 2, 2);
+  NT_TRI(128, 64, 32, 2, 2);
+  TN_GRAM(128, 64, 16, 2, 2);
+  TN_GRAM(128, 128, 16, 2, 2);
+  TN_GRAM(128, 64, 32, 2, 2);
+  return 0;
+}
