@@ -32,9 +32,11 @@ struct Layer {
   long off_Z, off_var, off_ls, off_qmu, off_qsqrt;   // offsets in the flat parameter vector
   double *meanW = nullptr, *meanb = nullptr;
   double *Kuu, *Lu, *Linv, *Lq, *qmu_p, *Wcat, *u;   // derived small matrices (padded to Mp)
+  double *Scat;                                      // [D*Mp x Mp]: S'_d = W_d W_d^T - I stacked (backward only)
+  double *Z1;                                        // [Mp x (D_in+1)] = [Z | 1]
   double *dLq, *dqmu_p;                              // d ELBO / d (Lq, q_mu) of the last grad_finish
-  long acc_Q, acc_dW, acc_du, acc_dZ, acc_dls, acc_dvar;
-  double *Kt, *Ct, *Tt, *mean, *var, *F, *mbar, *vbar;   // chunk workspace
+  long acc_Q, acc_G, acc_du, acc_GX, acc_x2, acc_dvar;
+  double *Kt, *Ct, *cnp, *tnp, *mean0, *mean, *var, *F, *mbar, *vbar;   // chunk workspace
 };
 
 constexpr int kNCat = 4;
@@ -73,7 +75,7 @@ struct dgp_ctx {
   char* ws = nullptr;
   size_t ws_cap = 0;
   long ws_limit = 96L << 30;
-  double *Cbar = nullptr, *Kbar = nullptr, *xbar = nullptr;
+  double *Cbar = nullptr, *Kbar = nullptr, *xbar = nullptr, *Gt = nullptr, *X1 = nullptr, *R1 = nullptr;
   double* sm[10] = {nullptr};
   std::vector<double*> zs_dev;
   std::vector<size_t> zs_cap;
@@ -174,6 +176,22 @@ int G(dgp_ctx* ctx, int cat, GemmOp op, long M, long N, long K, const double* A,
   return DGP_OK;
 }
 
+int GX(dgp_ctx* ctx, int cat, GemmOp op, GemmArgs a, double flops = 0.0, double bytes = 0.0) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return DGP_OK;
+  ProfScope ps(ctx, cat, flops, bytes);
+  HIPCHK(gemm_f64(ctx->st, op, a));
+  return DGP_OK;
+}
+
+GemmArgs mk(long M, long N, long K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
+            double alpha = 1.0, int beta = 0) {
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  a.sA = a.sB = a.sC = 0; a.batch = 1; a.splits = 1; a.ksplit = 0; a.alpha = alpha; a.beta = beta;
+  a.tri = TRI_NONE; a.triblk = 0;
+  return a;
+}
+
 int pick_splits(long Mrows, long Ncols, long K) {
   const long tiles = ((Mrows + 127) / 128) * ((Ncols + 63) / 64);
   long s = 1536 / (tiles > 0 ? tiles : 1);
@@ -210,7 +228,7 @@ int grow(dgp_ctx* ctx, double** p, size_t* cap, size_t n) {
 void free_model(dgp_ctx* ctx) {
   for (auto& l : ctx->L) {
     dev_free(l.Kuu); dev_free(l.Lu); dev_free(l.Linv); dev_free(l.Lq); dev_free(l.qmu_p); dev_free(l.Wcat);
-    dev_free(l.u); dev_free(l.dLq); dev_free(l.dqmu_p);
+    dev_free(l.u); dev_free(l.Scat); dev_free(l.Z1); dev_free(l.dLq); dev_free(l.dqmu_p);
   }
   ctx->L.clear();
   dev_free(ctx->params); dev_free(ctx->grad); dev_free(ctx->adam_m); dev_free(ctx->adam_v);
@@ -237,28 +255,35 @@ size_t carve(dgp_ctx* ctx, char* base, long Nc, int S, bool train) {
     return p;
   };
   const int nl = (int)ctx->L.size();
-  long Pmax_Mp = 0, T_max = 0, xb_max = 0;
+  long Pmax_Mp = 0, pl_max = 0, xb_max = 0, x1_max = 0;
   for (int l = 0; l < nl; ++l) {
     Layer& y = ctx->L[l];
     const long Pl = (l == 0) ? Nc : (long)S * Nc;
     Pmax_Mp = std::max(Pmax_Mp, Pl * y.Mp);
-    T_max = std::max(T_max, Pl * y.d.D_out * y.Mp);
+    pl_max = std::max(pl_max, Pl * (y.Mp / 32) * (1 + y.d.D_out));
     xb_max = std::max(xb_max, (long)S * Nc * y.d.D_in);
+    x1_max = std::max(x1_max, Pl * (y.d.D_in + 1));
   }
-  double *sKt = nullptr, *sCt = nullptr, *sTt = nullptr;
-  if (!train) { sKt = take(Pmax_Mp); sCt = take(Pmax_Mp); sTt = take(T_max); }
+  double *sKt = nullptr, *sCt = nullptr, *sPl = nullptr;
+  if (!train) { sKt = take(Pmax_Mp); sCt = take(Pmax_Mp); }
+  sPl = take(pl_max);                                      // row-norm partial planes: consumed within the layer
   for (int l = 0; l < nl; ++l) {
     Layer& y = ctx->L[l];
     const long Pl = (l == 0) ? Nc : (long)S * Nc;
     const long D = y.d.D_out;
-    if (train) { y.Kt = take(Pl * y.Mp); y.Ct = take(Pl * y.Mp); y.Tt = take(Pl * D * y.Mp); }
-    else { y.Kt = sKt; y.Ct = sCt; y.Tt = sTt; }
-    y.mean = take(Pl * D); y.var = take(Pl * D);
+    if (train) { y.Kt = take(Pl * y.Mp); y.Ct = take(Pl * y.Mp); }
+    else { y.Kt = sKt; y.Ct = sCt; }
+    y.cnp = sPl;
+    y.tnp = sPl ? sPl + Pl * (y.Mp / 32) : nullptr;
+    y.mean0 = take(Pl * D); y.mean = take(Pl * D); y.var = take(Pl * D);
     y.F = take((long)S * Nc * D);
     if (train) { y.mbar = take(Pl * D); y.vbar = take(Pl * D); }
     else { y.mbar = y.vbar = nullptr; }
   }
-  if (train) { ctx->Cbar = take(Pmax_Mp); ctx->Kbar = take(Pmax_Mp); ctx->xbar = take(xb_max); }
+  if (train) {
+    ctx->Cbar = take(Pmax_Mp); ctx->Kbar = take(Pmax_Mp); ctx->Gt = take(Pmax_Mp); ctx->xbar = take(xb_max);
+    ctx->X1 = take(x1_max); ctx->R1 = take(x1_max);
+  }
   return off;
 }
 
@@ -295,7 +320,7 @@ int upload_zs(dgp_ctx* ctx, const double* const* zs, int S, long Ntot) {
 inline const double* P(dgp_ctx* ctx, long off) { return ctx->params + off; }
 
 // ------------------------------------------------------------------------------- prep: small matrices + KL
-int prep(dgp_ctx* ctx) {
+int prep(dgp_ctx* ctx, bool train = false) {
   HIPCHK(hipMemsetAsync(ctx->scal, 0, 4 * sizeof(double), ctx->st));
   for (auto& y : ctx->L) {
     const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
@@ -313,6 +338,13 @@ int prep(dgp_ctx* ctx) {
       RET(G(ctx, 2, GEMM_NN, Mp, D, Mp, y.Linv, Mp, y.qmu_p, D, y.u, D, 1.0, 0));
     }
     HIPCHK(layer_kl(ctx->st, y.Wcat, y.u, y.Lq, y.Lu, M, Mp, D, y.d.white, ctx->scal));
+    if (train) {   // S'_d = W_d W_d^T - I  (symmetric), stacked [D*Mp x Mp]
+      GemmArgs a = mk(Mp, Mp, Mp, y.Wcat, (long)D * Mp, y.Wcat, (long)D * Mp, y.Scat, Mp);
+      a.batch = D; a.sA = Mp; a.sB = Mp; a.sC = MM;
+      RET(GX(ctx, 2, GEMM_NT, a));
+      HIPCHK(sub_identity(ctx->st, y.Scat, M, Mp, D));
+      HIPCHK(make_z1(ctx->st, P(ctx, y.off_Z), M, Mp, Din, y.Z1));
+    }
   }
   return DGP_OK;
 }
@@ -338,22 +370,28 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
     const long Pl = dedup ? Nc : (long)S * Nc;
     const double* Xin = dedup ? Xsrc : ctx->L[l - 1].F;
     const long row0 = dedup ? n0 : 0;
+    const int nplane = Mp / 32;
     {
       ProfScope ps(ctx, 1, 0, (double)Pl * (Mp + Din) * 8);
       HIPCHK(rbf_kuf(ctx->st, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din, y.Kt));
     }
     const double tri1 = (double)Pl * Mp * (Mp + 1.0);   // 2 * M(M+1)/2 flops per point
-    RET(G(ctx, 0, GEMM_NT, Pl, Mp, Mp, y.Kt, Mp, y.Linv, Mp, y.Ct, Mp, 1.0, 0, 1, 0, 0, 0, 1, TRI_B_UPPER, Mp, tri1,
-          (double)Pl * Mp * 16));
-    RET(G(ctx, 0, GEMM_NN, Pl, (long)D * Mp, Mp, y.Ct, Mp, y.Wcat, (long)D * Mp, y.Tt, (long)D * Mp, 1.0, 0, 1, 0, 0, 0,
-          1, TRI_B_LOWER, Mp, tri1 * D, (double)Pl * Mp * 8 * (1 + D)));
+    {  // c = Lu^-1 k  and |c|^2 partials
+      GemmArgs a = mk(Pl, Mp, Mp, y.Kt, Mp, y.Linv, Mp, y.Ct, Mp);
+      a.tri = TRI_B_UPPER; a.triblk = Mp; a.epi = 2; a.rowsq = y.cnp; a.rowsq_ld = Pl;
+      RET(GX(ctx, 0, GEMM_NT, a, tri1, (double)Pl * Mp * 16));
+    }
+    {  // t_d = W_d^T c is never stored: only |t_d|^2 partials leave the kernel
+      GemmArgs a = mk(Pl, (long)D * Mp, Mp, y.Ct, Mp, y.Wcat, (long)D * Mp, nullptr, (long)D * Mp);
+      a.tri = TRI_B_LOWER; a.triblk = Mp; a.epi = 1; a.rowsq = y.tnp; a.rowsq_ld = Pl;
+      RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 8));
+    }
+    RET(GX(ctx, 0, GEMM_NN, mk(Pl, D, Mp, y.Ct, Mp, y.u, D, y.mean0, D), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
     {
-      ProfScope ps(ctx, 1, 0, (double)Pl * Mp * 8 * (1 + D));
-      const bool last = (l == nl - 1);
-      (void)last;
-      HIPCHK(var_mean_sample(ctx->st, y.Ct, y.Tt, y.u, Xin, row0, Pl, Nc, S, dedup ? 1 : 0, M, Mp, Din, D,
-                             P(ctx, y.off_var), y.d.mean_kind, y.meanW, y.meanb,
-                             zsrc_of(ctx, l, use_zs, seed, n_goff, Ntot), n0, y.mean, y.var, y.F));
+      ProfScope ps(ctx, 1, 0, (double)Pl * nplane * 8 * (1 + D));
+      HIPCHK(finalize_layer(ctx->st, y.cnp, y.tnp, nplane, y.mean0, Xin, row0, Pl, Nc, S, dedup ? 1 : 0, Din, D,
+                            P(ctx, y.off_var), y.d.mean_kind, y.meanW, y.meanb,
+                            zsrc_of(ctx, l, use_zs, seed, n_goff, Ntot), n0, y.mean, y.var, y.F));
     }
   }
   return DGP_OK;
@@ -370,32 +408,53 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     const long Pl = dedup ? Nc : (long)S * Nc;
     const double* Xin = dedup ? ctx->X : ctx->L[l - 1].F;
     const long row0 = dedup ? n0 : 0;
-    const long DM = (long)D * Mp;
+    const long DM = (long)D * Mp, MM = (long)Mp * Mp;
     const double tri1 = (double)Pl * Mp * (Mp + 1.0);
-    {
-      ProfScope ps(ctx, 1, 0, (double)Pl * DM * 16);
-      HIPCHK(scale_T(ctx->st, y.Tt, y.vbar, Pl, Mp, D));
+    {  // dC = sum_d 2 vbar_d .* (C S'_d)      (A operand scaled on the fly; K = D*Mp re-reads C per block)
+      GemmArgs a = mk(Pl, Mp, DM, y.Ct, Mp, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);
+      a.ascale = y.vbar; a.as_ld = D; a.a_kblk = Mp; a.ascale_mode = 1;
+      RET(GX(ctx, 0, GEMM_NN, a, 2.0 * tri1 * D, (double)Pl * Mp * 16));
     }
-    RET(G(ctx, 0, GEMM_NT, Pl, Mp, DM, y.Tt, DM, y.Wcat, DM, ctx->Cbar, Mp, 1.0, 0, 1, 0, 0, 0, 1, TRI_B_UPPER, Mp,
-          tri1 * D, (double)Pl * Mp * 8 * (1 + D)));
-    {
-      ProfScope ps(ctx, 1, 0, (double)Pl * Mp * 24);
-      HIPCHK(cbar_fix(ctx->st, ctx->Cbar, y.Ct, y.mbar, y.vbar, y.u, Pl, Mp, D));
-    }
-    RET(G(ctx, 0, GEMM_NN, Pl, Mp, Mp, ctx->Cbar, Mp, y.Linv, Mp, ctx->Kbar, Mp, 1.0, 0, 1, 0, 0, 0, 1, TRI_B_LOWER, Mp,
-          tri1, (double)Pl * Mp * 16));
-    // reductions over the chunk's points (accumulate into the all-reduce buffer)
-    RET(G(ctx, 0, GEMM_TN, Mp, DM, Pl, y.Ct, Mp, y.Tt, DM, acc + y.acc_dW, DM, 1.0, 1, 1, 0, 0, 0,
-          pick_splits(Mp, DM, Pl), TRI_OUT_LOWER, Mp, tri1 * D, (double)Pl * Mp * 8 * (1 + D)));
-    RET(G(ctx, 0, GEMM_TN, Mp, Mp, Pl, ctx->Kbar, Mp, y.Ct, Mp, acc + y.acc_Q, Mp, 1.0, 1, 1, 0, 0, 0,
-          pick_splits(Mp, Mp, Pl), TRI_OUT_LOWER, Mp, tri1, (double)Pl * Mp * 16));
-    RET(G(ctx, 0, GEMM_TN, Mp, D, Pl, y.Ct, Mp, y.mbar, D, acc + y.acc_du, D, 1.0, 1, 1, 0, 0, 0,
-          pick_splits(Mp, D, Pl), TRI_NONE, 0, 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
     {
       ProfScope ps(ctx, 1, 0, (double)Pl * Mp * 16);
-      HIPCHK(rbf_kuf_bwd(ctx->st, ctx->Kbar, y.Kt, Xin, row0, Pl, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls),
-                         M, Mp, Din, D, y.d.mean_kind, y.meanW, y.mbar, l > 0 ? 1 : 0, ctx->xbar, acc + y.acc_dZ,
-                         acc + y.acc_dls, acc + y.acc_dvar));
+      HIPCHK(cbar_fix(ctx->st, ctx->Cbar, y.mbar, y.u, Pl, Mp, D));
+    }
+    {
+      GemmArgs a = mk(Pl, Mp, Mp, ctx->Cbar, Mp, y.Linv, Mp, ctx->Kbar, Mp);
+      a.tri = TRI_B_LOWER; a.triblk = Mp;
+      a.emul = y.Kt; a.C2 = ctx->Gt;                        // g = dK .* K for the RBF backward
+      RET(GX(ctx, 0, GEMM_NN, a, tri1, (double)Pl * Mp * 32));
+    }
+    // reductions over the chunk's points (accumulate into the all-reduce buffer)
+    {  // G_d = sum_p vbar_pd c_p c_p^T   (lower triangle; dW_d = 2 G_d W_d after the all-reduce)
+      GemmArgs a = mk(Mp, Mp, Pl, y.Ct, Mp, y.Ct, Mp, acc + y.acc_G, Mp, 1.0, 1);
+      a.batch = D; a.sC = MM; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits(Mp, Mp * (long)D, Pl);
+      a.ascale = y.vbar; a.as_ld = D; a.ascale_mode = 2;
+      RET(GX(ctx, 0, GEMM_TN, a, tri1 * D, (double)Pl * Mp * 8));
+    }
+    {
+      GemmArgs a = mk(Mp, Mp, Pl, ctx->Kbar, Mp, y.Ct, Mp, acc + y.acc_Q, Mp, 1.0, 1);
+      a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits(Mp, Mp, Pl);
+      RET(GX(ctx, 0, GEMM_TN, a, tri1, (double)Pl * Mp * 16));
+    }
+    {
+      GemmArgs a = mk(Mp, D, Pl, y.Ct, Mp, y.mbar, D, acc + y.acc_du, D, 1.0, 1);
+      a.splits = pick_splits(Mp, D, Pl);
+      RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
+    }
+    {  // RBF backward through Kuf: two skinny contractions of g with [Z | 1] and [X | 1]
+      const int w1 = Din + 1;
+      {
+        ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 16);
+        HIPCHK(make_x1(ctx->st, Xin, row0, Pl, Din, ctx->X1));
+      }
+      RET(GX(ctx, 0, GEMM_NN, mk(Pl, w1, Mp, ctx->Gt, Mp, y.Z1, w1, ctx->R1, w1), 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
+      GemmArgs a = mk(Mp, w1, Pl, ctx->Gt, Mp, ctx->X1, w1, acc + y.acc_GX, w1, 1.0, 1);
+      a.splits = pick_splits(Mp, w1, Pl);
+      RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
+      ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 24);
+      HIPCHK(xbar_finish(ctx->st, ctx->R1, ctx->X1, Pl, P(ctx, y.off_ls), Din, D, y.d.mean_kind, y.meanW, y.mbar,
+                         l > 0 ? 1 : 0, ctx->xbar, acc + y.acc_x2));
     }
     if (l > 0) {
       Layer& w = ctx->L[l - 1];
@@ -487,15 +546,15 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
   int Mpmax = 0, Dmax = 0;
   for (int l = 0; l < n_layers; ++l) {
     const dgp_layer_desc& d = layers[l];
-    if (d.D_in <= 0 || d.D_out <= 0 || d.M <= 0 || d.M > 1024 || d.D_out > 65535 || d.kernel_kind != DGP_KERNEL_RBF ||
+    if (d.D_in <= 0 || d.D_in > 64 || d.D_out <= 0 || d.M <= 0 || d.M > 1024 || d.D_out > 65535 || d.kernel_kind != DGP_KERNEL_RBF ||
         d.mean_kind < 0 || d.mean_kind > 2)
-      return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: unsupported layer description (RBF kernel, M <= 1024)");
+      return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: unsupported layer description (RBF kernel, M <= 1024, D_in <= 64)");
     if (l > 0 && d.D_in != layers[l - 1].D_out) return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: layer dims do not chain");
     if (d.mean_kind == DGP_MEAN_IDENTITY && d.D_in != d.D_out)
       return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: identity mean needs D_in == D_out");
     Layer y{};
     y.d = d;
-    y.Mp = (int)round_up(d.M, 16);
+    y.Mp = (int)round_up(d.M, 64);   // tiles of 64 columns never straddle an output block
     y.off_Z = off; off += (long)d.M * d.D_in;
     y.off_var = off; off += 1;
     y.off_ls = off; off += d.D_in;
@@ -503,10 +562,10 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
     y.off_qsqrt = off; off += (long)d.D_out * d.M * d.M;
     const long MM = (long)y.Mp * y.Mp;
     y.acc_Q = aoff; aoff += MM;
-    y.acc_dW = aoff; aoff += MM * d.D_out;
+    y.acc_G = aoff; aoff += MM * d.D_out;
     y.acc_du = aoff; aoff += round_up((long)y.Mp * d.D_out, 2);
-    y.acc_dZ = aoff; aoff += round_up((long)d.M * d.D_in, 2);
-    y.acc_dls = aoff; aoff += round_up(d.D_in, 2);
+    y.acc_GX = aoff; aoff += round_up((long)y.Mp * (d.D_in + 1), 2);
+    y.acc_x2 = aoff; aoff += round_up(d.D_in, 2);
     y.acc_dvar = aoff; aoff += 2;
     Mpmax = std::max(Mpmax, y.Mp);
     Dmax = std::max(Dmax, d.D_out);
@@ -543,7 +602,7 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
     const int D = y.d.D_out;
     RET(dev_alloc(ctx, &y.Kuu, MM)); RET(dev_alloc(ctx, &y.Lu, MM)); RET(dev_alloc(ctx, &y.Linv, MM));
     RET(dev_alloc(ctx, &y.Lq, MM * D)); RET(dev_alloc(ctx, &y.qmu_p, (long)y.Mp * D));
-    RET(dev_alloc(ctx, &y.Wcat, MM * D)); RET(dev_alloc(ctx, &y.u, (long)y.Mp * D));
+    RET(dev_alloc(ctx, &y.Wcat, MM * D)); RET(dev_alloc(ctx, &y.u, (long)y.Mp * D)); RET(dev_alloc(ctx, &y.Scat, MM * D)); RET(dev_alloc(ctx, &y.Z1, (long)y.Mp * (y.d.D_in + 1)));
     RET(dev_alloc(ctx, &y.dLq, MM * D)); RET(dev_alloc(ctx, &y.dqmu_p, (long)y.Mp * D));
     if (y.d.mean_kind == DGP_MEAN_LINEAR) {
       y.meanW = ctx->mean_params + moff; moff += (long)y.d.D_in * D;
@@ -681,7 +740,7 @@ int dgp_grad_partial(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const
   HIPCHK(hipSetDevice(ctx->device));
   ctx->grad_ready = false;
   if (zs) RET(upload_zs(ctx, zs, S, ctx->N));
-  RET(prep(ctx));
+  RET(prep(ctx, true));
   HIPCHK(hipMemsetAsync(ctx->acc, 0, ctx->n_acc * 8, ctx->st));
   long Nc = 0;
   RET(ensure_ws(ctx, ctx->N, S, true, &Nc));
@@ -723,8 +782,14 @@ int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out) {
     const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
     const long MM = (long)Mp * Mp, DM = (long)D * Mp;
     double *T1 = ctx->sm[0], *T2 = ctx->sm[1], *T3 = ctx->sm[2], *T4 = ctx->sm[3], *Sm = ctx->sm[4];
-    double *dW = acc + y.acc_dW, *du = acc + y.acc_du, *Q = acc + y.acc_Q;
+    double *Gd = acc + y.acc_G, *du = acc + y.acc_du, *Q = acc + y.acc_Q, *dW = ctx->sm[5];
     ProfScope ps(ctx, 2, 0, 0);
+    {  // dW_d = 2 G_d W_d  (G_d symmetric, accumulated as its lower triangle)
+      HIPCHK(symmetrize_lower(ctx->st, Gd, Mp, D));
+      GemmArgs a = mk(Mp, Mp, Mp, Gd, Mp, y.Wcat, DM, dW, DM, 2.0, 0);
+      a.batch = D; a.sA = MM; a.sB = Mp; a.sC = Mp;
+      RET(GX(ctx, 2, GEMM_NN, a));
+    }
     HIPCHK(wbar_total(ctx->st, dW, y.Wcat, du, y.u, M, Mp, D));
     if (!y.d.white) {
       RET(G(ctx, 2, GEMM_NT, Mp, Mp, DM, dW, DM, y.Wcat, DM, T1, Mp, 1.0, 0));
@@ -747,11 +812,10 @@ int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out) {
     HIPCHK(phi_tril_halfdiag(ctx->st, T3, Mp, 1));
     RET(G(ctx, 2, GEMM_NN, Mp, Mp, Mp, T3, Mp, y.Linv, Mp, T4, Mp, 1.0, 0));
     RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Linv, Mp, T4, Mp, Sm, Mp, 1.0, 0));
+    HIPCHK(rbf_kuf_bwd_finish(ctx->st, acc + y.acc_GX, acc + y.acc_x2, acc + y.acc_dvar, P(ctx, y.off_Z), P(ctx, y.off_var),
+                              P(ctx, y.off_ls), M, Din, g + y.off_Z, g + y.off_ls, g + y.off_var));
     HIPCHK(rbf_kuu_bwd(ctx->st, Sm, y.Kuu, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
-                       acc + y.acc_dZ, acc + y.acc_dls, acc + y.acc_dvar));
-    HIPCHK(copy_mat(ctx->st, acc + y.acc_dZ, g + y.off_Z, (long)M * Din));
-    HIPCHK(copy_mat(ctx->st, acc + y.acc_dvar, g + y.off_var, 1));
-    HIPCHK(copy_mat(ctx->st, acc + y.acc_dls, g + y.off_ls, Din));
+                       g + y.off_Z, g + y.off_ls, g + y.off_var));
     HIPCHK(unpack_q_grads(ctx->st, y.dLq, y.dqmu_p, M, Mp, D, g + y.off_qsqrt, g + y.off_qmu));
   }
   HIPCHK(copy_mat(ctx->st, acc + 1, g + ctx->n_params - 1, 1));

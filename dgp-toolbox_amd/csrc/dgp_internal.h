@@ -42,6 +42,13 @@ hipError_t symmetrize_axpy(hipStream_t st, const double* Gm, const double* Pinv,
                            int Mp, int batch);                              // out = Pinv + two_gamma * 0.5 (G + G^T)
 hipError_t natgrad_mu(hipStream_t st, const double* Sn, const double* g_qmu_p, double gamma, double* qmu_p, int M,
                       int Mp, int D);                                       // mu_d -= gamma * Sn_d g_d
+// S'cat[d] <- S'cat[d] - I on the valid M x M block; Gs <- symmetric completion of the lower-triangular G (batched)
+// Z1 = [Z | 1] padded to Mp rows; and the Kuf part of dZ / dls / dvar from GX = g^T [X | 1] and sum_p x^2 rs
+hipError_t make_z1(hipStream_t st, const double* Z, int M, int Mp, int Din, double* Z1);
+hipError_t rbf_kuf_bwd_finish(hipStream_t st, const double* GX, const double* x2rs, const double* vsum, const double* Z,
+                              const double* var, const double* ls, int M, int Din, double* dZ, double* dls, double* dvar);
+hipError_t sub_identity(hipStream_t st, double* S, int M, int Mp, int batch);
+hipError_t symmetrize_lower(hipStream_t st, double* G, int Mp, int batch);
 hipError_t sub_scalars(hipStream_t st, const double* a, const double* b, double* out);   // out = a - b
 hipError_t store_q(hipStream_t st, const double* Lq, const double* qmu_p, int M, int Mp, int D, double* q_sqrt,
                    double* q_mu);
@@ -57,12 +64,13 @@ struct ZSource {           // where the N(0,1) draws of one layer come from
 
 hipError_t rbf_kuf(hipStream_t st, const double* Xin, long P, long x_row0, const double* Z, const double* var,
                    const double* ls, int M, int Mp, int Din, double* Kt);
-// var/mean/sample stage of a layer (layers.py:249-278 + utils.py:41). `dedup`: the P rows are the Nc data
-// points of the first layer (identical for every sample s); F is always written for all S*Nc rows.
-hipError_t var_mean_sample(hipStream_t st, const double* Ct, const double* Tt, const double* u, const double* Xin,
-                           long x_row0, long P, long Nc, int S, int dedup, int M, int Mp, int Din, int D,
-                           const double* kvar, int mean_kind, const double* meanW, const double* meanb, ZSource zsrc,
-                           long n_chunk0, double* mean, double* var, double* F);
+// var/mean/sample stage of a layer (layers.py:249-278 + utils.py:41) from the GEMM epilogue partials.
+// `dedup`: the P rows are the Nc data points of the first layer (identical for every sample s); F is always
+// written for all S*Nc rows.
+hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, int nplane, const double* mean0,
+                          const double* Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
+                          const double* kvar, int mean_kind, const double* meanW, const double* meanb, ZSource zsrc,
+                          long n_chunk0, double* mean, double* var, double* F);
 // Gaussian variational expectations (gpflow Gaussian, via utils.py:89-93) + seeds of the backward pass
 hipError_t gauss_lik(hipStream_t st, const double* mean, const double* var, const double* Y, long y_row0, long Nc,
                      int S, int dedup, int Dy, const double* lik_var, double* acc_elbo, double* acc_dlik,
@@ -70,13 +78,11 @@ hipError_t gauss_lik(hipStream_t st, const double* mean, const double* var, cons
 // fold dF into (mbar, vbar) of the producing layer; sums over s when dedup
 hipError_t fold_sample_grad(hipStream_t st, const double* Fbar, const double* var, long Nc, int S, int dedup, int D,
                             ZSource zsrc, long n_chunk0, double* mbar, double* vbar, double* acc_dkvar);
-hipError_t scale_T(hipStream_t st, double* Tt, const double* vbar, long P, int Mp, int D);
-hipError_t cbar_fix(hipStream_t st, double* Cbar, const double* Ct, const double* mbar, const double* vbar,
-                    const double* u, long P, int Mp, int D);
-hipError_t rbf_kuf_bwd(hipStream_t st, const double* Kbar, const double* Kt, const double* Xin, long x_row0, long P,
-                       const double* Z, const double* var, const double* ls, int M, int Mp, int Din, int D,
+hipError_t cbar_fix(hipStream_t st, double* Cbar, const double* mbar, const double* u, long P, int Mp, int D);
+hipError_t make_x1(hipStream_t st, const double* Xin, long x_row0, long P, int Din, double* X1);     // [X | 1]
+hipError_t xbar_finish(hipStream_t st, const double* R1, const double* X1, long P, const double* ls, int Din, int D,
                        int mean_kind, const double* meanW, const double* mbar, int want_xbar, double* xbar,
-                       double* acc_dZ, double* acc_dls, double* acc_dvar);
+                       double* acc_x2rs);
 hipError_t expand_rows(hipStream_t st, const double* src, long Nc, int S, int D, int dedup, double* dst, long Ntot,
                        long n0);
 hipError_t lik_predict_var(hipStream_t st, double* var, long n, const double* lik_var);

@@ -52,6 +52,20 @@ struct GemmArgs {
   int beta;          // 0: overwrite, 1: accumulate (non-atomic; ignored when splits > 1)
   int tri;
   long triblk;
+  // optional row scaling of the physical A tile (fused elementwise work, no extra HBM pass):
+  //   ascale_mode 1 (A not transposed): A[m][k] = ascale[m*as_ld + k / a_kblk] * Aphys[m][k % a_kblk]
+  //                                     (K = nblk * a_kblk re-reads the same physical columns per block)
+  //   ascale_mode 2 (A transposed):     A[k][m] = ascale[k*as_ld + batch] * Aphys[k][m]
+  const double* ascale = nullptr;
+  long as_ld = 0, a_kblk = 1;
+  int ascale_mode = 0;
+  // epilogue: 0 store C; 1 only row sums of squares; 2 both.  rowsq[(tile_col*WC + wave_col)*rowsq_ld + row]
+  int epi = 0;
+  double* rowsq = nullptr;
+  long rowsq_ld = 0;
+  // optional second output C2 = (alpha * A B) .* E  (same shape / leading dimension as C; used for g = dK .* K)
+  const double* emul = nullptr;
+  double* C2 = nullptr;
 };
 
 template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int VB>
@@ -74,20 +88,23 @@ struct GemmCfg {
 // global -> registers for one operand tile (rows x contiguous cols), zero-filled outside [rmax, cmax)
 template <int ROWS, int COLS, int V, int TPR, int RPP, int PASS>
 __device__ __forceinline__ void tile_load(double (&reg)[PASS][V], const double* __restrict__ base, long ld,
-                                          long r0, long c0, long rmax, long cmax, int tid) {
+                                          long r0, long c0, long rmax, long cmax, int tid,
+                                          const double* __restrict__ sc = nullptr, long sc_ld = 0, long sc_col = 0) {
   const int tr = tid / TPR, tc = (tid % TPR) * V;
 #pragma unroll
   for (int p = 0; p < PASS; ++p) {
     const int r = p * RPP + tr;
     const long gr = r0 + r, gc = c0 + tc;
     const bool ok = (r < ROWS) && (gr < rmax) && (gc < cmax);
+    double f = 1.0;
+    if (sc != nullptr) f = ok ? sc[gr * sc_ld + sc_col] : 0.0;
     if constexpr (V == 2) {
       d2_t v = {0.0, 0.0};
       if (ok) v = *reinterpret_cast<const d2_t*>(base + gr * ld + gc);
-      reg[p][0] = v[0];
-      reg[p][1] = v[1];
+      reg[p][0] = v[0] * f;
+      reg[p][1] = v[1] * f;
     } else {
-      reg[p][0] = ok ? base[gr * ld + gc] : 0.0;
+      reg[p][0] = (ok ? base[gr * ld + gc] : 0.0) * f;
     }
   }
 }
@@ -174,10 +191,21 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   };
   auto gload = [&](long kt) {
     const long k0 = kabs_of(kt), kend = kend_of(kt);
-    if constexpr (TA)
-      tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, k0, m0, kend, g.M, tid);
-    else
-      tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, m0, k0, g.M, kend, tid);
+    if constexpr (TA) {
+      if (g.ascale_mode == 2)
+        tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, k0, m0, kend, g.M, tid,
+                                                                                      g.ascale, g.as_ld, (long)bz);
+      else
+        tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, k0, m0, kend, g.M, tid);
+    } else {
+      if (g.ascale_mode == 1) {
+        const long kb = k0 / g.a_kblk, kp = k0 - kb * g.a_kblk;     // BK divides a_kblk: a k-tile never straddles blocks
+        tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, m0, kp, g.M, g.a_kblk, tid,
+                                                                                      g.ascale, g.as_ld, kb);
+      } else {
+        tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, m0, k0, g.M, kend, tid);
+      }
+    }
     if constexpr (TB)
       tile_load<Cfg::B_ROWS, Cfg::B_COLS, VB, Cfg::B_TPR, Cfg::B_RPP, Cfg::B_PASS>(rb, B, g.ldb, n0, k0, g.N, kend, tid);
     else
@@ -248,6 +276,24 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   }
 
   // ---- epilogue: acc[i][j][r] of lane l is C[rowblk*16 + 4*((l&15)>>2) + (l>>4)][colblk*16 + ((l&15) + 4r) & 15]
+  if (g.epi != 0) {
+    // per-row sums of squares over this wave's columns: a lane holds 4 values of its row per fragment, the
+    // 4 lanes l&3 = 0..3 of a quad hold the rest of that row's 16 columns
+    double* __restrict__ rs = g.rowsq + ((long)tn * WC + wc) * g.rowsq_ld;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      double q = 0.0;
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const double v = g.alpha * acc[i][j][r]; q += v * v; }
+      q += __shfl_xor(q, 1);
+      q += __shfl_xor(q, 2);
+      const long row = m0 + (long)(i * WR + wr) * 16 + 4 * (li >> 2) + lk;
+      if ((li & 3) == 0 && row < g.M) rs[row] = q;
+    }
+    if (g.epi == 1) return;
+  }
   const bool atomic = g.splits > 1;
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
@@ -263,6 +309,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
           if (atomic) unsafeAtomicAdd(p, v);
           else if (g.beta) *p += v;
           else *p = v;
+          if (g.C2 != nullptr) g.C2[row * g.ldc + col] = v * g.emul[row * g.ldc + col];
         }
       }
     }

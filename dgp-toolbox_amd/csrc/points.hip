@@ -66,6 +66,9 @@ __device__ __forceinline__ void block_atomic_add(double v, double* dst, double* 
 __global__ void rbf_kuf_kernel(const double* __restrict__ Xin, long P, long x_row0, const double* __restrict__ Z,
                                const double* __restrict__ var, const double* __restrict__ ls, int M, int Mp, int Din,
                                double* __restrict__ Kt) {
+  __shared__ double ils[64];
+  for (int j = threadIdx.x; j < Din; j += blockDim.x) ils[j] = 1.0 / ls[j];
+  __syncthreads();
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= P * Mp) return;
   const long p = idx / Mp;
@@ -76,7 +79,7 @@ __global__ void rbf_kuf_kernel(const double* __restrict__ Xin, long P, long x_ro
     const double* z = Z + (long)m * Din;
     double r2 = 0.0;
     for (int j = 0; j < Din; ++j) {
-      const double d = (x[j] - z[j]) / ls[j];
+      const double d = (x[j] - z[j]) * ils[j];
       r2 += d * d;
     }
     v = var[0] * exp(-0.5 * r2);
@@ -94,61 +97,56 @@ hipError_t rbf_kuf(hipStream_t st, const double* Xin, long P, long x_row0, const
 }
 
 // ---------------------------------------------------------------------------------------- var / mean / sample
-// One wave per point.  var = k_diag - |c|^2 + |W_d^T c|^2  (triangular form of layers.py:254-276),
-// mean = c^T u_d + mean_function(x)  (layers.py:249,278),  F = mean + z sqrt(var + jitter)  (utils.py:41).
-__global__ __launch_bounds__(256) void var_mean_sample_kernel(
-    const double* __restrict__ Ct, const double* __restrict__ Tt, const double* __restrict__ u,
-    const double* __restrict__ Xin, long x_row0, long P, long Nc, int S, int dedup, int M, int Mp, int Din, int D,
+// Finalises a layer from the GEMM epilogue partials:  cn = |c|^2 and tn_d = |W_d^T c|^2 arrive as per-wave
+// row sums of squares (planes of P doubles), mean0 = c^T u_d from a skinny GEMM.
+//   var = k_diag - |c|^2 + |W_d^T c|^2   (triangular form of layers.py:254-276)
+//   mean = c^T u_d + mean_function(x)    (layers.py:249,278)
+//   F = mean + z sqrt(var + jitter)      (utils.py:41)
+// One thread per (d, p), p fastest (coalesced plane reads).
+__global__ __launch_bounds__(256) void finalize_layer_kernel(
+    const double* __restrict__ cnp, const double* __restrict__ tnp, int nplane, const double* __restrict__ mean0,
+    const double* __restrict__ Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
     const double* __restrict__ kvar, int mean_kind, const double* __restrict__ meanW, const double* __restrict__ meanb,
     ZSource zsrc, long n_chunk0, double* __restrict__ mean, double* __restrict__ var, double* __restrict__ F) {
-  const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= P) return;
-  const int lane = threadIdx.x & 63;
-  const double* c = Ct + p * Mp;
-  double cn = 0.0;
-  for (int m = lane; m < Mp; m += 64) { const double v = c[m]; cn += v * v; }
-  cn = wave_sum(cn);
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * D) return;
+  const int d = (int)(idx / P);
+  const long p = idx % P;
+  double cn = 0.0, tn = 0.0;
+  for (int q = 0; q < nplane; ++q) {
+    cn += cnp[(long)q * P + p];
+    tn += tnp[((long)d * nplane + q) * P + p];
+  }
   const double* x = Xin + (x_row0 + p) * Din;
-  const double kv = kvar[0];
-  for (int d = 0; d < D; ++d) {
-    const double* t = Tt + (p * D + d) * Mp;
-    double tn = 0.0, mu = 0.0;
-    for (int m = lane; m < Mp; m += 64) {
-      const double tv = t[m];
-      tn += tv * tv;
-      if (m < M) mu += c[m] * u[(long)m * D + d];
-    }
-    tn = wave_sum(tn);
-    mu = wave_sum(mu);
-    double mf = 0.0;
-    if (mean_kind == 1) mf = x[d];
-    else if (mean_kind == 2) {
-      for (int j = 0; j < Din; ++j) mf += x[j] * meanW[(long)j * D + d];
-      mf += meanb[d];
-    }
-    const double mv = mu + mf, vv = kv - cn + tn;
-    if (lane == 0) { mean[p * D + d] = mv; var[p * D + d] = vv; }
-    if (F) {
-      const double sd = sqrt(vv + kJitter);
-      if (dedup) {
-        for (int s = lane; s < S; s += 64)
-          F[((long)s * Nc + p) * D + d] = mv + draw_z(zsrc, s, n_chunk0 + p, d, D) * sd;
-      } else if (lane == 0) {
-        const int s = (int)(p / Nc);
-        const long i = p % Nc;
-        F[p * D + d] = mv + draw_z(zsrc, s, n_chunk0 + i, d, D) * sd;
-      }
+  double mf = 0.0;
+  if (mean_kind == 1) mf = x[d];
+  else if (mean_kind == 2) {
+    for (int j = 0; j < Din; ++j) mf += x[j] * meanW[(long)j * D + d];
+    mf += meanb[d];
+  }
+  const double mv = mean0[p * D + d] + mf, vv = kvar[0] - cn + tn;
+  mean[p * D + d] = mv;
+  var[p * D + d] = vv;
+  if (F) {
+    const double sd = sqrt(vv + kJitter);
+    if (dedup) {
+      for (int s = 0; s < S; ++s) F[((long)s * Nc + p) * D + d] = mv + draw_z(zsrc, s, n_chunk0 + p, d, D) * sd;
+    } else {
+      const int s = (int)(p / Nc);
+      const long i = p % Nc;
+      F[p * D + d] = mv + draw_z(zsrc, s, n_chunk0 + i, d, D) * sd;
     }
   }
 }
 
-hipError_t var_mean_sample(hipStream_t st, const double* Ct, const double* Tt, const double* u, const double* Xin,
-                           long x_row0, long P, long Nc, int S, int dedup, int M, int Mp, int Din, int D,
-                           const double* kvar, int mean_kind, const double* meanW, const double* meanb, ZSource zsrc,
-                           long n_chunk0, double* mean, double* var, double* F) {
-  if (P == 0) return hipSuccess;
-  hipLaunchKernelGGL(var_mean_sample_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, Ct, Tt, u, Xin, x_row0, P,
-                     Nc, S, dedup, M, Mp, Din, D, kvar, mean_kind, meanW, meanb, zsrc, n_chunk0, mean, var, F);
+hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, int nplane, const double* mean0,
+                          const double* Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
+                          const double* kvar, int mean_kind, const double* meanW, const double* meanb, ZSource zsrc,
+                          long n_chunk0, double* mean, double* var, double* F) {
+  const long n = P * D;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(finalize_layer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cnp, tnp, nplane, mean0, Xin,
+                     x_row0, P, Nc, S, dedup, Din, D, kvar, mean_kind, meanW, meanb, zsrc, n_chunk0, mean, var, F);
   LAUNCH_CHECK();
 }
 
@@ -248,154 +246,80 @@ hipError_t fold_sample_grad(hipStream_t st, const double* Fbar, const double* va
   LAUNCH_CHECK();
 }
 
-// ---------------------------------------------------------------------------------------- sTt = 2 vbar * Tt
-__global__ void scale_T_kernel(double* __restrict__ Tt, const double* __restrict__ vbar, long rows, int Mp) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 2 doubles
-  const long half = Mp / 2;
-  if (idx >= rows * half) return;
-  const long r = idx / half;
-  d2_t* p = reinterpret_cast<d2_t*>(Tt) + idx;
-  const double s = 2.0 * vbar[r];
-  d2_t v = *p;
-  v[0] *= s;
-  v[1] *= s;
-  *p = v;
-}
-hipError_t scale_T(hipStream_t st, double* Tt, const double* vbar, long P, int Mp, int D) {
-  const long n = P * D * (Mp / 2);
-  if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(scale_T_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Tt, vbar, P * D, Mp);
-  LAUNCH_CHECK();
-}
-
-// dC += u mbar^T - 2 (sum_d vbar) C      (SURVEY App. C step 3 in whitened form)
-__global__ void cbar_fix_kernel(double* __restrict__ Cbar, const double* __restrict__ Ct, const double* __restrict__ mbar,
-                                const double* __restrict__ vbar, const double* __restrict__ u, long P, int Mp, int D) {
+// ---------------------------------------------------------------------------------------- dC += mbar u^T
+// dC_p = u mbar_p + sum_d 2 vbar_pd (W_d W_d^T - I) c_p   (whitened); the second term is
+// the GEMM  [2 vbar .* C] * S'cat  with S'_d = W_d W_d^T - I; this kernel adds the first.
+__global__ void cbar_fix_kernel(double* __restrict__ Cbar, const double* __restrict__ mbar, const double* __restrict__ u,
+                                long P, int Mp, int D) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= P * Mp) return;
   const long p = idx / Mp;
   const int m = (int)(idx % Mp);
-  double w = 0.0, a = 0.0;
-  for (int d = 0; d < D; ++d) {
-    w += vbar[p * D + d];
-    a += mbar[p * D + d] * u[(long)m * D + d];
-  }
-  Cbar[idx] += a - 2.0 * w * Ct[idx];
+  double a = 0.0;
+  for (int d = 0; d < D; ++d) a += mbar[p * D + d] * u[(long)m * D + d];
+  Cbar[idx] += a;
 }
-hipError_t cbar_fix(hipStream_t st, double* Cbar, const double* Ct, const double* mbar, const double* vbar,
-                    const double* u, long P, int Mp, int D) {
+hipError_t cbar_fix(hipStream_t st, double* Cbar, const double* mbar, const double* u, long P, int Mp, int D) {
   const long n = P * Mp;
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(cbar_fix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Cbar, Ct, mbar, vbar, u, P,
-                     Mp, D);
+  hipLaunchKernelGGL(cbar_fix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Cbar, mbar, u, P, Mp, D);
   LAUNCH_CHECK();
 }
 
 // ---------------------------------------------------------------------------------------- RBF backward (Kuf)
-// g = dK .* K;  dx_pj = sum_m g (z_mj - x_pj)/l_j^2 (+ mean-function path);  dz_mj -= sum_p g (z_mj - x_pj)/l_j^2;
-// dl_j += sum g (z_mj - x_pj)^2 / l_j^3;  dvar += sum g / var      
-// Persistent blocks: a tile of TP points of g is staged in LDS; the (m,j) sums are kept in LDS across
-// tiles and flushed once per block with one atomic per entry.
-__global__ __launch_bounds__(256) void rbf_kuf_bwd_kernel(
-    const double* __restrict__ Kbar, const double* __restrict__ Kt, const double* __restrict__ Xin, long x_row0, long P,
-    const double* __restrict__ Z, const double* __restrict__ var, const double* __restrict__ ls, int M, int Mp, int Din,
-    int D, int mean_kind, const double* __restrict__ meanW, const double* __restrict__ mbar, int want_xbar,
-    double* __restrict__ xbar, double* __restrict__ acc_dZ, double* __restrict__ acc_dls, double* __restrict__ acc_dvar,
-    int TP, int lds_sums) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int ldg = Mp + 2;
-  double* g = sm;                       // [TP][Mp+2]
-  double* xs = g + (long)TP * ldg;      // [TP][Din]
-  double* zsum = xs + (long)TP * Din;   // [M*Din]   (only when lds_sums)
-  double* lsum = zsum + (lds_sums ? (long)M * Din : 0);
-  __shared__ double sh[4];
-  const int tid = threadIdx.x;
-  const long npair = (long)M * Din;
-  if (lds_sums)
-    for (long q = tid; q < npair; q += 256) { zsum[q] = 0.0; lsum[q] = 0.0; }
-  double vacc = 0.0;
-  const long ntile = (P + TP - 1) / TP;
-  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-    const long p0 = tile * TP;
-    const int np = (int)min((long)TP, P - p0);
-    __syncthreads();
-    for (long idx = tid; idx < (long)TP * Mp; idx += 256) {
-      const int pt = (int)(idx / Mp), m = (int)(idx % Mp);
-      double v = 0.0;
-      if (pt < np && m < M) v = Kbar[(p0 + pt) * Mp + m] * Kt[(p0 + pt) * Mp + m];
-      g[(long)pt * ldg + m] = v;
-      vacc += v;
-    }
-    for (int idx = tid; idx < TP * Din; idx += 256) {
-      const int pt = idx / Din, j = idx % Din;
-      xs[idx] = (pt < np) ? Xin[(x_row0 + p0 + pt) * Din + j] : 0.0;
-    }
-    __syncthreads();
-    // inducing-point side
-    for (long q = tid; q < npair; q += 256) {
-      const int m = (int)(q / Din), j = (int)(q % Din);
-      const double zmj = Z[q];
-      double za = 0.0, la = 0.0;
-      for (int pt = 0; pt < np; ++pt) {
-        const double gv = g[(long)pt * ldg + m];
-        const double dl = zmj - xs[pt * Din + j];
-        za += gv * dl;
-        la += gv * dl * dl;
-      }
-      if (lds_sums) { zsum[q] += za; lsum[q] += la; }
-      else {
-        const double l = ls[j];
-        unsafeAtomicAdd(acc_dZ + q, -za / (l * l));
-        unsafeAtomicAdd(acc_dls + j, la / (l * l * l));
-      }
-    }
-    // input side
-    if (want_xbar) {
-      for (int idx = tid; idx < np * Din; idx += 256) {
-        const int pt = idx / Din, j = idx % Din;
-        const double xv = xs[idx], l = ls[j];
-        double a = 0.0;
-        for (int m = 0; m < M; ++m) a += g[(long)pt * ldg + m] * (Z[(long)m * Din + j] - xv);
-        a /= (l * l);
-        const double* mb = mbar + (p0 + pt) * D;
-        if (mean_kind == 1) a += mb[j];
-        else if (mean_kind == 2)
-          for (int d = 0; d < D; ++d) a += meanW[(long)j * D + d] * mb[d];
-        xbar[(p0 + pt) * Din + j] = a;
-      }
-    }
-  }
-  __syncthreads();
-  if (lds_sums) {
-    for (long q = tid; q < npair; q += 256) {
-      const int j = (int)(q % Din);
-      const double l = ls[j];
-      unsafeAtomicAdd(acc_dZ + q, -zsum[q] / (l * l));
-      unsafeAtomicAdd(acc_dls + j, lsum[q] / (l * l * l));
-    }
-  }
-  block_atomic_add(vacc / var[0], acc_dvar, sh);
+// With g = dK .* K (second output of the dK GEMM):  
+//   dx_pj = (sum_m g z_mj - x_pj sum_m g) / l_j^2 (+ mean-function path)     <- R1 = g [Z | 1]
+//   dz_mj = -(z_mj sum_p g - sum_p g x_pj) / l_j^2                           <- GX = g^T [X | 1]  (over points)
+//   dl_j  = (sum_m z_mj^2 cs_m - 2 sum_m z_mj GX_mj + sum_p x_pj^2 rs_p) / l_j^3,   dvar = sum_m cs_m / var
+// so the contractions run in the GEMM engine and only thin element-wise kernels remain.
+__global__ void make_x1_kernel(const double* __restrict__ Xin, long x_row0, long P, int Din, double* __restrict__ X1) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = Din + 1;
+  if (idx >= P * w) return;
+  const long p = idx / w;
+  const int j = (int)(idx % w);
+  X1[idx] = (j < Din) ? Xin[(x_row0 + p) * Din + j] : 1.0;
+}
+hipError_t make_x1(hipStream_t st, const double* Xin, long x_row0, long P, int Din, double* X1) {
+  const long n = P * (Din + 1);
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(make_x1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Xin, x_row0, P, Din, X1);
+  LAUNCH_CHECK();
 }
 
-hipError_t rbf_kuf_bwd(hipStream_t st, const double* Kbar, const double* Kt, const double* Xin, long x_row0, long P,
-                       const double* Z, const double* var, const double* ls, int M, int Mp, int Din, int D, int mean_kind,
-                       const double* meanW, const double* mbar, int want_xbar, double* xbar, double* acc_dZ,
-                       double* acc_dls, double* acc_dvar) {
-  if (P == 0) return hipSuccess;
-  int TP = 32;
-  while (TP > 4 && (long)TP * (Mp + 2) * 8 > 65536) TP >>= 1;
-  const int lds_sums = ((long)M * Din * 16 <= 65536) ? 1 : 0;
-  const size_t lds = ((size_t)TP * (Mp + 2) + (size_t)TP * Din + (lds_sums ? 2 * (size_t)M * Din : 0)) * 8;
-  const long ntile = (P + TP - 1) / TP;
-  long blocks = ntile < 1024 ? ntile : 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(rbf_kuf_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024 - 64);
-    attr_set = true;
+__global__ __launch_bounds__(256) void xbar_finish_kernel(const double* __restrict__ R1, const double* __restrict__ X1, long P,
+                                                          const double* __restrict__ ls, int Din, int D, int mean_kind,
+                                                          const double* __restrict__ meanW, const double* __restrict__ mbar,
+                                                          int want_xbar, double* __restrict__ xbar,
+                                                          double* __restrict__ acc_x2rs) {
+  __shared__ double sh[4];
+  const int w = Din + 1;
+  // one block handles all points for a fixed j (grid.y = Din): coalescing is secondary here (72 B per point)
+  const int j = blockIdx.y;
+  const double l = ls[j], il2 = 1.0 / (l * l);
+  double x2 = 0.0;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+    const double rs = R1[p * w + Din], x = X1[p * w + j];
+    x2 += x * x * rs;
+    if (want_xbar) {
+      double a = (R1[p * w + j] - x * rs) * il2;
+      const double* mb = mbar + p * D;
+      if (mean_kind == 1) a += mb[j];
+      else if (mean_kind == 2)
+        for (int d = 0; d < D; ++d) a += meanW[(long)j * D + d] * mb[d];
+      xbar[p * Din + j] = a;
+    }
   }
-  hipLaunchKernelGGL(rbf_kuf_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, st, Kbar, Kt, Xin, x_row0, P, Z, var, ls,
-                     M, Mp, Din, D, mean_kind, meanW, mbar, want_xbar, xbar, acc_dZ, acc_dls, acc_dvar, TP, lds_sums);
+  block_atomic_add(x2, acc_x2rs + j, sh);
+}
+hipError_t xbar_finish(hipStream_t st, const double* R1, const double* X1, long P, const double* ls, int Din, int D,
+                       int mean_kind, const double* meanW, const double* mbar, int want_xbar, double* xbar,
+                       double* acc_x2rs) {
+  if (P == 0) return hipSuccess;
+  long blocks = (P + 255) / 256;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(xbar_finish_kernel, dim3((unsigned)blocks, Din), dim3(256), 0, st, R1, X1, P, ls, Din, D, mean_kind, meanW,
+                     mbar, want_xbar, xbar, acc_x2rs);
   LAUNCH_CHECK();
 }
 

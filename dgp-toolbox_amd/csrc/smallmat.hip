@@ -226,6 +226,78 @@ hipError_t copy_mat(hipStream_t st, const double* src, double* dst, long n) {
   LAUNCH_CHECK();
 }
 
+__global__ void make_z1_kernel(const double* __restrict__ Z, int M, int Mp, int Din, double* __restrict__ Z1) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = Din + 1;
+  if (idx >= (long)Mp * w) return;
+  const int m = (int)(idx / w), j = (int)(idx % w);
+  Z1[idx] = (m < M) ? (j < Din ? Z[(long)m * Din + j] : 1.0) : 0.0;
+}
+hipError_t make_z1(hipStream_t st, const double* Z, int M, int Mp, int Din, double* Z1) {
+  const long n = (long)Mp * (Din + 1);
+  hipLaunchKernelGGL(make_z1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Z, M, Mp, Din, Z1);
+  LAUNCH_CHECK();
+}
+
+// writes (not accumulates) the Kuf + K_diag parts of d ELBO / d (Z, lengthscales, variance); one block per j
+__global__ __launch_bounds__(256) void rbf_kuf_bwd_finish_kernel(const double* __restrict__ GX, const double* __restrict__ x2rs,
+                                                                 const double* __restrict__ vsum, const double* __restrict__ Z,
+                                                                 const double* __restrict__ var, const double* __restrict__ ls,
+                                                                 int M, int Din, double* __restrict__ dZ,
+                                                                 double* __restrict__ dls, double* __restrict__ dvar) {
+  __shared__ double sh[16];
+  const int j = blockIdx.x, w = Din + 1;
+  const double l = ls[j];
+  double la = 0.0, va = 0.0;
+  for (int m = threadIdx.x; m < M; m += blockDim.x) {
+    const double cs = GX[(long)m * w + Din], gx = GX[(long)m * w + j], z = Z[(long)m * Din + j];
+    dZ[(long)m * Din + j] = -(z * cs - gx) / (l * l);
+    la += z * z * cs - 2.0 * z * gx;
+    va += cs;
+  }
+  for (int o = 32; o > 0; o >>= 1) { la += __shfl_down(la, o); va += __shfl_down(va, o); }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { sh[wv] = la; sh[8 + wv] = va; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double lt = 0.0, vt = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { lt += sh[i]; vt += sh[8 + i]; }
+    dls[j] = (lt + x2rs[j]) / (l * l * l);
+    if (j == 0) dvar[0] = vt / var[0] + vsum[0];
+  }
+}
+hipError_t rbf_kuf_bwd_finish(hipStream_t st, const double* GX, const double* x2rs, const double* vsum, const double* Z,
+                              const double* var, const double* ls, int M, int Din, double* dZ, double* dls, double* dvar) {
+  hipLaunchKernelGGL(rbf_kuf_bwd_finish_kernel, dim3(Din), dim3(256), 0, st, GX, x2rs, vsum, Z, var, ls, M, Din, dZ, dls, dvar);
+  LAUNCH_CHECK();
+}
+
+__global__ void sub_identity_kernel(double* __restrict__ S, int M, int Mp, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int i = (int)((idx / Mp) % Mp), j = (int)(idx % Mp);
+  if (i >= M || j >= M) S[idx] = 0.0;            // padding: W_pad = I so W W^T - I = 0 there
+  else if (i == j) S[idx] -= 1.0;
+}
+hipError_t sub_identity(hipStream_t st, double* S, int M, int Mp, int batch) {
+  const long n = (long)batch * Mp * Mp;
+  hipLaunchKernelGGL(sub_identity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, M, Mp, n);
+  LAUNCH_CHECK();
+}
+
+__global__ void symmetrize_lower_kernel(double* __restrict__ G, int Mp, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long b = idx / ((long)Mp * Mp);
+  const int i = (int)((idx / Mp) % Mp), j = (int)(idx % Mp);
+  if (j > i) G[idx] = G[b * Mp * Mp + (long)j * Mp + i];
+}
+hipError_t symmetrize_lower(hipStream_t st, double* G, int Mp, int batch) {
+  const long n = (long)batch * Mp * Mp;
+  hipLaunchKernelGGL(symmetrize_lower_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G, Mp, n);
+  LAUNCH_CHECK();
+}
+
 __global__ void sub_scalars_kernel(const double* a, const double* b, double* out) { out[0] = a[0] - b[0]; }
 hipError_t sub_scalars(hipStream_t st, const double* a, const double* b, double* out) {
   hipLaunchKernelGGL(sub_scalars_kernel, dim3(1), dim3(1), 0, st, a, b, out);
