@@ -126,7 +126,12 @@ __device__ __forceinline__ void tile_store(const double (&reg)[PASS][V], double*
   }
 }
 
-template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int VB>
+// FAST: the host guarantees that every tile of the launch is interior (M % BM == 0, N % BN == 0, every
+// k-range a multiple of BK, 16-byte aligned operands): the loader then keeps one running pointer per operand,
+// issues unconditional 16-byte loads and carries no predicates — the generic loader's ~330 non-MFMA
+// instructions per k-tile made the loop issue-bound (two waves share a SIMD's issue port with the MFMAs).
+// SCALED (FAST only): A-operand row scaling of GemmArgs::ascale_mode.
+template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int VB, bool FAST = false, bool SCALED = false>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   using Cfg = GemmCfg<TA, TB, BM, BN, BK, WR, WC, VA, VB>;
   constexpr int FM = Cfg::FM, FN = Cfg::FN;
@@ -181,16 +186,12 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 
   double ra[Cfg::A_PASS][VA], rb[Cfg::B_PASS][VB];
 
-  auto kabs_of = [&](long kt) -> long {
-    const long kb = kt / ktiles_per_blk, kk = kt % ktiles_per_blk;
-    return kb * kblen + klo + kk * BK;
-  };
-  auto kend_of = [&](long kt) -> long {
-    const long kb = kt / ktiles_per_blk;
-    return kb * kblen + khi;
-  };
-  auto gload = [&](long kt) {
-    const long k0 = kabs_of(kt), kend = kend_of(kt);
+  // k-tile cursor advanced incrementally: no integer divisions in the loop (a 64-bit divide is hundreds of
+  // instructions on the GPU and would sit between the MFMA blocks).  kb = triangular block, kk = tile in block,
+  // ablk / aoff = block and offset of A's wrapped K (ascale_mode 1).
+  long cur_kb = 0, cur_kk = 0, cur_ablk = 0, cur_aoff = 0;
+  auto gload = [&]() {                                     // loads the tile at the cursor, then advances it
+    const long k0 = cur_kb * kblen + klo + cur_kk * BK, kend = cur_kb * kblen + khi;
     if constexpr (TA) {
       if (g.ascale_mode == 2)
         tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, k0, m0, kend, g.M, tid,
@@ -198,10 +199,9 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       else
         tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, k0, m0, kend, g.M, tid);
     } else {
-      if (g.ascale_mode == 1) {
-        const long kb = k0 / g.a_kblk, kp = k0 - kb * g.a_kblk;     // BK divides a_kblk: a k-tile never straddles blocks
-        tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, m0, kp, g.M, g.a_kblk, tid,
-                                                                                      g.ascale, g.as_ld, kb);
+      if (g.ascale_mode == 1) {                            // BK divides a_kblk: a k-tile never straddles blocks
+        tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, m0, cur_aoff, g.M, g.a_kblk, tid,
+                                                                                      g.ascale, g.as_ld, cur_ablk);
       } else {
         tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, m0, k0, g.M, kend, tid);
       }
@@ -210,6 +210,10 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       tile_load<Cfg::B_ROWS, Cfg::B_COLS, VB, Cfg::B_TPR, Cfg::B_RPP, Cfg::B_PASS>(rb, B, g.ldb, n0, k0, g.N, kend, tid);
     else
       tile_load<Cfg::B_ROWS, Cfg::B_COLS, VB, Cfg::B_TPR, Cfg::B_RPP, Cfg::B_PASS>(rb, B, g.ldb, k0, n0, kend, g.N, tid);
+    cur_kk += 1;
+    if (cur_kk == ktiles_per_blk) { cur_kk = 0; cur_kb += 1; }
+    cur_aoff += BK;
+    if (cur_aoff >= g.a_kblk) { cur_aoff = 0; cur_ablk += 1; }
   };
   auto sstore = [&](int buf) {
     double* as = smem + buf * (Cfg::AS_SZ + Cfg::BS_SZ);
@@ -218,21 +222,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     tile_store<Cfg::B_ROWS, Cfg::B_COLS, VB, Cfg::B_TPR, Cfg::B_RPP, Cfg::B_PASS, Cfg::LDB_S>(rb, bs, tid);
   };
 
-  if (ktiles > 0) {
-    gload(0);
-    sstore(0);
-  }
-  __syncthreads();
-
-  // Main loop: one straight-line MFMA path.  The triangular structure is exploited at tile level only
-  // (k-range per 128x64 tile, tiles above the diagonal skipped): in-loop predication made hipcc move the
-  // accumulators between VGPRs and AGPRs around every MFMA (measured 2.3x slower).
-  for (long kt = 0; kt < ktiles; ++kt) {
-    const int cur = (int)(kt & 1);
-    const bool more = (kt + 1 < ktiles);
-#ifndef DGP_ABLATE_GLOBAL
-    if (more) gload(kt + 1);                       // next tile's global loads fly under the MFMAs
-#endif
+  auto compute = [&](int cur) {
     const double* as = smem + cur * (Cfg::AS_SZ + Cfg::BS_SZ);
     const double* bs = as + Cfg::AS_SZ;
 #pragma unroll
@@ -269,10 +259,99 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
             acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[i], fb[j][r], acc[i][j][r], 0, 0, 0);
 #endif
     }
-#ifndef DGP_ABLATE_GLOBAL
-    if (more) sstore(cur ^ 1);
-#endif
+  };
+
+  if constexpr (!FAST) {
+    if (ktiles > 0) {
+      gload();
+      sstore(0);
+    }
     __syncthreads();
+    // Generic main loop (edge tiles, unaligned operands): predicated loads.  The triangular structure is
+    // exploited at tile level only (k-range per tile, tiles above the diagonal skipped): in-loop predication
+    // of the MFMAs made hipcc move the accumulators between VGPRs and AGPRs around every MFMA (2.3x slower).
+    for (long kt = 0; kt < ktiles; ++kt) {
+      const int cur = (int)(kt & 1);
+      const bool more = (kt + 1 < ktiles);
+#ifndef DGP_ABLATE_GLOBAL
+      if (more) gload();                             // next tile's global loads fly under the MFMAs
+#endif
+      compute(cur);
+#ifndef DGP_ABLATE_GLOBAL
+      if (more) sstore(cur ^ 1);
+#endif
+      __syncthreads();
+    }
+  } else {
+    // ---- interior fast path: running pointers, unconditional 16-byte loads, no predicates ----
+    static_assert(!FAST || (VA == 2 && VB == 2), "fast path is vectorised");
+    const int a_tr = tid / Cfg::A_TPR, a_tc = (tid % Cfg::A_TPR) * 2;
+    const int b_tr = tid / Cfg::B_TPR, b_tc = (tid % Cfg::B_TPR) * 2;
+    const bool wrap = (!TA) && SCALED;                         // ascale_mode 1: K wraps around a_kblk physical columns
+    const double* pa = TA ? A + (klo + a_tr) * g.lda + m0 + a_tc : A + (m0 + a_tr) * g.lda + (wrap ? 0 : klo) + a_tc;
+    const double* pb = TB ? B + (n0 + b_tr) * g.ldb + klo + b_tc : B + (klo + b_tr) * g.ldb + n0 + b_tc;
+    const long a_pass = (long)Cfg::A_RPP * g.lda, b_pass = (long)Cfg::B_RPP * g.ldb;
+    const long a_kstride = TA ? g.lda : 1, b_kstride = TB ? 1 : g.ldb;
+    // scale source: mode 1 -> ascale[(m0 + row)*as_ld + d], constant within a d-block; mode 2 -> ascale[k*as_ld + batch]
+    const double* ps = nullptr;
+    long s_pass = 0, s_kstride = 0;
+    if constexpr (SCALED) {
+      ps = TA ? g.ascale + (klo + a_tr) * g.as_ld + bz : g.ascale + (m0 + a_tr) * g.as_ld;
+      s_pass = (long)Cfg::A_RPP * g.as_ld;
+      s_kstride = TA ? g.as_ld : 0;
+    }
+    const long jump = kblen - (ktiles_per_blk - 1) * BK;      // k advance when crossing a triangular block boundary
+    const long tiles_per_wrap = wrap ? g.a_kblk / BK : 0;
+    long kk_in_blk = 0, kk_in_wrap = 0;
+    d2_t fra[Cfg::A_PASS], frb[Cfg::B_PASS];
+    double fsc[Cfg::A_PASS];
+    auto fload = [&]() {
+#pragma unroll
+      for (int p = 0; p < Cfg::A_PASS; ++p) fra[p] = *reinterpret_cast<const d2_t*>(pa + p * a_pass);
+#pragma unroll
+      for (int p = 0; p < Cfg::B_PASS; ++p) frb[p] = *reinterpret_cast<const d2_t*>(pb + p * b_pass);
+      if constexpr (SCALED) {
+#pragma unroll
+        for (int p = 0; p < Cfg::A_PASS; ++p) fsc[p] = ps[p * s_pass];
+      }
+      // advance the cursors (uniform, scalar)
+      long ka = BK, kbs = BK;
+      kk_in_blk += 1;
+      if (kk_in_blk == ktiles_per_blk) { kk_in_blk = 0; ka = jump; kbs = jump; }
+      if (wrap) {
+        kk_in_wrap += 1;
+        if (kk_in_wrap == tiles_per_wrap) { kk_in_wrap = 0; ka = BK - g.a_kblk; if constexpr (SCALED) ps += 1; }
+      }
+      pa += ka * a_kstride;
+      pb += kbs * b_kstride;
+      if constexpr (SCALED) ps += BK * s_kstride;
+    };
+    auto fstore = [&](int buf) {
+      double* as = smem + buf * (Cfg::AS_SZ + Cfg::BS_SZ);
+      double* bs = as + Cfg::AS_SZ;
+#pragma unroll
+      for (int p = 0; p < Cfg::A_PASS; ++p) {
+        d2_t v = fra[p];
+        if constexpr (SCALED) { v[0] *= fsc[p]; v[1] *= fsc[p]; }
+        *reinterpret_cast<d2_t*>(as + (p * Cfg::A_RPP + a_tr) * Cfg::LDA_S + a_tc) = v;
+      }
+#pragma unroll
+      for (int p = 0; p < Cfg::B_PASS; ++p)
+        *reinterpret_cast<d2_t*>(bs + (p * Cfg::B_RPP + b_tr) * Cfg::LDB_S + b_tc) = frb[p];
+    };
+    if (ktiles > 0) {
+      fload();
+      fstore(0);
+    }
+    __syncthreads();
+    for (long kt = 0; kt < ktiles; ++kt) {
+      const int cur = (int)(kt & 1);
+      const bool more = (kt + 1 < ktiles);
+      if (more) fload();
+      compute(cur);
+      if (more) fstore(cur ^ 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: acc[i][j][r] of lane l is C[rowblk*16 + 4*((l&15)>>2) + (l>>4)][colblk*16 + ((l&15) + 4r) & 15]

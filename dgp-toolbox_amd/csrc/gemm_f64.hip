@@ -3,12 +3,19 @@
 
 namespace dgp {
 
-template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int VB>
-static hipError_t launch(hipStream_t st, const GemmArgs& a) {
+template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int VB, bool FAST = false, bool SCALED = false>
+static hipError_t launch(hipStream_t st, GemmArgs a) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.batch <= 0) return hipSuccess;
+  if (a.splits > 1) {   // ksplit must be a multiple of BK so that split boundaries coincide with k-tiles
+    long per = (a.K + a.splits - 1) / a.splits;
+    per = ((per + BK - 1) / BK) * BK;
+    a.ksplit = per;
+    a.splits = (int)((a.K + per - 1) / per);
+  }
+  if (a.splits < 1) a.splits = 1;
   const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  if (tiles <= 0 || a.batch <= 0) return hipSuccess;
   dim3 grid((unsigned)tiles, (unsigned)(a.batch * a.splits), 1);
-  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, VA, VB>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, VA, VB, FAST, SCALED>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -17,13 +24,12 @@ static inline bool vec2_ok(const double* p, long ld, long extent, long bstride, 
          (batch <= 1 || bstride % 2 == 0);
 }
 
+// generic (predicated) path for any shape
 template <bool TA, bool TB>
-static hipError_t dispatch(hipStream_t st, const GemmArgs& a) {
-  // contiguous-direction extents: A is k-contiguous (N) or m-contiguous (T); B is n- (N) or k-contiguous (T)
-  const bool va = vec2_ok(a.A, a.lda, TA ? a.M : a.K, a.sA, a.batch);
+static hipError_t launch_generic(hipStream_t st, const GemmArgs& a) {
+  const bool va = vec2_ok(a.A, a.lda, TA ? a.M : (a.ascale_mode == 1 ? a.a_kblk : a.K), a.sA, a.batch);
   const bool vb = vec2_ok(a.B, a.ldb, TB ? a.K : a.N, a.sB, a.batch);
-  const bool skinny = a.N <= 16;
-  if (!skinny) {
+  if (a.N > 16) {
     if (va && vb) return launch<TA, TB, 128, 64, 16, 2, 2, 2, 2>(st, a);
     return launch<TA, TB, 128, 64, 16, 2, 2, 1, 1>(st, a);
   }
@@ -31,18 +37,61 @@ static hipError_t dispatch(hipStream_t st, const GemmArgs& a) {
   return launch<TA, TB, 128, 16, 16, 4, 1, 1, 1>(st, a);
 }
 
+template <bool TA, bool TB>
+static hipError_t launch_fast(hipStream_t st, const GemmArgs& a) {
+  if (a.ascale_mode == 0) return launch<TA, TB, 128, 64, 16, 2, 2, 2, 2, true, false>(st, a);
+  if constexpr (!TB) return launch<TA, TB, 128, 64, 16, 2, 2, 2, 2, true, true>(st, a);   // scaled A: NN (mode 1) / TN (mode 2)
+  else return hipErrorInvalidValue;
+}
+
+// Splits a product into an interior part run by the lean FAST kernel and edge strips run by the generic one.
+template <bool TA, bool TB>
+static hipError_t dispatch(hipStream_t st, const GemmArgs& a) {
+  constexpr long BM = 128, BN = 64, BK = 16;
+  const bool va = vec2_ok(a.A, a.lda, TA ? a.M : (a.ascale_mode == 1 ? a.a_kblk : a.K), a.sA, a.batch);
+  const bool vb = vec2_ok(a.B, a.ldb, TB ? a.K : a.N, a.sB, a.batch);
+  bool fast = va && vb && a.N > 16 && a.N % BN == 0 && (a.tri == TRI_NONE || (a.triblk % BN == 0 && a.triblk % BK == 0)) &&
+              (a.ascale_mode != 1 || (!TA && a.a_kblk % BK == 0 && a.K % a.a_kblk == 0)) && (a.ascale_mode != 2 || TA) &&
+              !(TB && a.ascale_mode != 0);
+  const long Mf = (a.M / BM) * BM;
+  if (!TA && a.K % BK != 0) fast = false;        // K is the contiguous direction of A: no K tail handling there
+  const long Kf = TA ? (a.K / BK) * BK : a.K;
+  if (!fast || Mf == 0 || Kf == 0) return launch_generic<TA, TB>(st, a);
+  hipError_t e;
+  {  // interior rows x aligned K
+    GemmArgs f = a;
+    f.M = Mf;
+    f.K = Kf;
+    if ((e = launch_fast<TA, TB>(st, f)) != hipSuccess) return e;
+  }
+  if (TA && Kf < a.K) {   // K tail of a reduction over points: accumulate on top of the fast part
+    GemmArgs t = a;
+    t.M = Mf;
+    t.A = a.A + Kf * a.lda;
+    t.B = a.B + Kf * a.ldb;
+    if (a.ascale_mode == 2) t.ascale = a.ascale + Kf * a.as_ld;
+    t.K = a.K - Kf;
+    t.splits = 1;
+    t.beta = 1;
+    if ((e = launch_generic<TA, TB>(st, t)) != hipSuccess) return e;
+  }
+  if (Mf < a.M) {         // remaining rows, full K
+    GemmArgs r = a;
+    r.M = a.M - Mf;
+    r.A = TA ? a.A + Mf : a.A + Mf * a.lda;
+    if (a.C) r.C = a.C + Mf * a.ldc;
+    if (a.C2) { r.C2 = a.C2 + Mf * a.ldc; r.emul = a.emul + Mf * a.ldc; }
+    if (a.rowsq) r.rowsq = a.rowsq + Mf;
+    if (a.ascale_mode == 1) r.ascale = a.ascale + Mf * a.as_ld;
+    if ((e = launch_generic<TA, TB>(st, r)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args) {
   GemmArgs a = args;
   if (a.splits < 1) a.splits = 1;
   if (a.batch < 1) a.batch = 1;
-  if (a.splits > 1) {
-    // ksplit must be a multiple of BK (=16) so that split boundaries coincide with k-tiles
-    long per = (a.K + a.splits - 1) / a.splits;
-    per = ((per + 15) / 16) * 16;
-    a.ksplit = per;
-    a.splits = (int)((a.K + per - 1) / per);
-    if (a.splits < 1) a.splits = 1;
-  }
   switch (op) {
     case GEMM_NN: return dispatch<false, false>(st, a);
     case GEMM_NT: return dispatch<false, true>(st, a);

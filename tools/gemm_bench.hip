@@ -4,10 +4,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include "gemm_f64.h"
 using namespace dgp;
 
-template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC>
+template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, bool FAST = false>
 double run(const char* name, long M, long N, long K, int splits, int tri, long triblk, double* dA, double* dB, double* dC,
            long lda, long ldb, long ldc, double work_frac) {
   GemmArgs a;
@@ -17,15 +18,30 @@ double run(const char* name, long M, long N, long K, int splits, int tri, long t
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   dim3 grid((unsigned)tiles, (unsigned)a.splits);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, 2, 2>), grid, dim3(256), 0, 0, a);
+  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, 2, 2, FAST, false>), grid, dim3(256), 0, 0, a);
   hipDeviceSynchronize();
   const int reps = 5;
   hipEventRecord(e0);
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, 2, 2>), grid, dim3(256), 0, 0, a);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, 2, 2, FAST, false>), grid, dim3(256), 0, 0, a);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+#ifdef DGP_CLOCK_STAMPS
+  {
+    long long* st; hipMalloc(&st, tiles * 16); hipMemset(st, 0, tiles * 16);
+    GemmArgs b = a; b.emul = reinterpret_cast<const double*>(st); b.C2 = nullptr;
+    hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, 2, 2, FAST, false>), grid, dim3(256), 0, 0, b);
+    hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, 2, 2, FAST, false>), grid, dim3(256), 0, 0, b);
+    hipDeviceSynchronize();
+    std::vector<long long> h(2 * tiles); hipMemcpy(h.data(), st, tiles * 16, hipMemcpyDeviceToHost);
+    std::vector<double> ghz;
+    for (long t = 0; t < tiles; ++t) if (h[2 * t + 1] > 0) ghz.push_back((double)h[2 * t] / ((double)h[2 * t + 1] / 100e6) / 1e9);
+    std::sort(ghz.begin(), ghz.end());
+    if (!ghz.empty()) printf("      in-kernel shader clock: median %.2f GHz (p10 %.2f, p90 %.2f) over %zu workgroups\n", ghz[ghz.size() / 2], ghz[ghz.size() / 10], ghz[ghz.size() * 9 / 10], ghz.size());
+    hipFree(st);
+  }
+#endif
   const double dense = 2.0 * M * N * K;
-  printf("%-44s %4dx%3dx%2d w%dx%d  %8.3f ms  dense-equiv %6.1f TF  executed(~%.0f%%) %6.1f TF\n", name, BM, BN, BK, WR, WC, ms,
+  printf("%-44s %s %4dx%3dx%2d w%dx%d  %8.3f ms  dense-equiv %6.1f TF  executed(~%.0f%%) %6.1f TF\n", name, FAST ? "FAST" : "gen ", BM, BN, BK, WR, WC, ms,
          dense / ms / 1e9, work_frac * 100, dense * work_frac / ms / 1e9);
   return ms;
 }
@@ -45,17 +61,14 @@ int main(int argc, char** argv) {
 #define NT_TRI(BM, BN, BK, WR, WC) run<false, true, BM, BN, BK, WR, WC>("NT  Cbar=sTt*Wcat^T tri (K=D*Mp)", P, Mp, DM, 1, TRI_B_UPPER, Mp, A, B, C, DM, DM, Mp, 0.5 + 0.5 * BN / Mp)
 #define TN_GRAM(BM, BN, BK, WR, WC) run<true, false, BM, BN, BK, WR, WC>("TN  dW=Ct^T*sTt (K=P) splits", Mp, DM, P, 48, TRI_OUT_LOWER, Mp, B + Mp * DM, A, C, Mp, DM, DM, 0.75)
   NN_DENSE(128, 64, 16, 2, 2);
-  NN_DENSE(128, 128, 16, 2, 2);
-  NN_DENSE(256, 64, 16, 4, 1);
-  NN_DENSE(128, 64, 32, 2, 2);
-  NN_DENSE(64, 64, 16, 2, 2);
+  run<false, false, 128, 64, 16, 2, 2, true>("NN  Tt=Ct*Wcat dense", P, DM, Mp, 1, 0, 0, A, B, C, Mp, DM, DM, 1.0);
   NN_TRI(128, 64, 16, 2, 2);
-  NN_TRI(128, 128, 16, 2, 2);
+  run<false, false, 128, 64, 16, 2, 2, true>("NN  Tt=Ct*Wcat tri", P, DM, Mp, 1, TRI_B_LOWER, Mp, A, B, C, Mp, DM, DM, 0.625);
+  run<false, false, 128, 64, 16, 2, 2, false>("NN  Cbar=C'*Scat dense K=D*Mp", P, Mp, DM, 1, 0, 0, A, B, C, DM, Mp, Mp, 1.0);
+  run<false, false, 128, 64, 16, 2, 2, true>("NN  Cbar=C'*Scat dense K=D*Mp", P, Mp, DM, 1, 0, 0, A, B, C, DM, Mp, Mp, 1.0);
   NT_TRI(128, 64, 16, 2, 2);
-  NT_TRI(128, 128, 16, 2, 2);
-  NT_TRI(128, 64, 32, 2, 2);
+  run<false, true, 128, 64, 16, 2, 2, true>("NT  Ct=Kt*Linv^T tri", P, Mp, Mp, 1, TRI_B_UPPER, Mp, A, B, C, Mp, Mp, Mp, 0.625);
   TN_GRAM(128, 64, 16, 2, 2);
-  TN_GRAM(128, 128, 16, 2, 2);
-  TN_GRAM(128, 64, 32, 2, 2);
+  run<true, false, 128, 64, 16, 2, 2, true>("TN  dW=Ct^T*sTt (K=P) splits", Mp, DM, P, 48, TRI_OUT_LOWER, Mp, B + Mp * DM, A, C, Mp, DM, DM, 0.75);
   return 0;
 }
