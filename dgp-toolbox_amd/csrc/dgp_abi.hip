@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -54,6 +55,7 @@ struct Prof {
 
 struct dgp_ctx {
   int device = 0;
+  int cu_count = 0;
   hipStream_t st = nullptr;
   bool own_stream = false;
   std::string err;
@@ -192,14 +194,45 @@ GemmArgs mk(long M, long N, long K, const double* A, long lda, const double* B, 
   return a;
 }
 
-int pick_splits(long Mrows, long Ncols, long K) {
-  const long tiles = ((Mrows + 127) / 128) * ((Ncols + 63) / 64);
-  long s = 1536 / (tiles > 0 ? tiles : 1);
-  const long kmax = K / 512;
-  if (s > kmax) s = kmax;
-  if (s < 1) s = 1;
-  if (s > 1024) s = 1024;
+// Split-K factor for the reductions over points: all active workgroups of such a launch run equally long, so
+// their number should fill whole rounds of the resident slots (2 workgroups per CU); `active_tiles` counts the
+// output tiles that survive the triangular skip, times the batch.
+int pick_splits_tiles(dgp_ctx* ctx, long active_tiles, long K, long row_bytes = 0) {
+  (void)ctx; (void)active_tiles;
+  // Chunk of points per split sized so that the streamed rows of one chunk (row_bytes each) stay in one XCD's
+  // 4 MiB L2 while all members of the chunk read them (see gemm_f64.h: XCD-grouped split-K mapping); the number
+  // of splits is a multiple of 8 (one group per XCD at a time).
+  // The members advance through their chunk in step, so L2 only has to hold the window between the fastest and
+  // the slowest member, not the whole chunk: a chunk of a few MiB keeps the hit rate while bounding the atomics.
+  if (row_bytes <= 0) row_bytes = 2048;
+  static long chunk_bytes = 0;
+  if (chunk_bytes == 0) {
+    const char* e = getenv("DGP_GRAM_CHUNK_BYTES");
+    chunk_bytes = e ? atol(e) : (8L << 20);
+    if (chunk_bytes < (1L << 16)) chunk_bytes = 1L << 16;
+  }
+  long chunk = chunk_bytes / row_bytes;
+  chunk = (chunk / 16) * 16;
+  if (chunk < 256) chunk = 256;
+  long s = (K + chunk - 1) / chunk;
+  s = ((s + 7) / 8) * 8;
+  if (s * 16 > K) s = 1;                               // tiny reductions: no split
+  if (s > 32760) s = 32760;
   return (int)s;
+}
+
+// number of 128x64 output tiles of an [Mp x Mp] lower-triangular target that are not skipped
+long lower_tiles(long Mp) {
+  long n = 0;
+  for (long m0 = 0; m0 < Mp; m0 += 128)
+    for (long n0 = 0; n0 < Mp; n0 += 64)
+      if (m0 + 127 >= n0) ++n;
+  return n;
+}
+
+int pick_splits(dgp_ctx* ctx, long Mrows, long Ncols, long K) {
+  const long tiles = ((Mrows + 127) / 128) * ((Ncols + 63) / 64);
+  return pick_splits_tiles(ctx, tiles, K, Mrows * 8);
 }
 
 // ------------------------------------------------------------------------------- memory helpers
@@ -428,18 +461,18 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     // reductions over the chunk's points (accumulate into the all-reduce buffer)
     {  // G_d = sum_p vbar_pd c_p c_p^T   (lower triangle; dW_d = 2 G_d W_d after the all-reduce)
       GemmArgs a = mk(Mp, Mp, Pl, y.Ct, Mp, y.Ct, Mp, acc + y.acc_G, Mp, 1.0, 1);
-      a.batch = D; a.sC = MM; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits(Mp, Mp * (long)D, Pl);
+      a.batch = D; a.sC = MM; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp) * D, Pl, (long)Mp * 8);
       a.ascale = y.vbar; a.as_ld = D; a.ascale_mode = 2;
       RET(GX(ctx, 0, GEMM_TN, a, tri1 * D, (double)Pl * Mp * 8));
     }
     {
       GemmArgs a = mk(Mp, Mp, Pl, ctx->Kbar, Mp, y.Ct, Mp, acc + y.acc_Q, Mp, 1.0, 1);
-      a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits(Mp, Mp, Pl);
+      a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp), Pl, (long)Mp * 16);
       RET(GX(ctx, 0, GEMM_TN, a, tri1, (double)Pl * Mp * 16));
     }
     {
       GemmArgs a = mk(Mp, D, Pl, y.Ct, Mp, y.mbar, D, acc + y.acc_du, D, 1.0, 1);
-      a.splits = pick_splits(Mp, D, Pl);
+      a.splits = pick_splits(ctx, Mp, D, Pl);
       RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
     }
     {  // RBF backward through Kuf: two skinny contractions of g with [Z | 1] and [X | 1]
@@ -450,7 +483,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       }
       RET(GX(ctx, 0, GEMM_NN, mk(Pl, w1, Mp, ctx->Gt, Mp, y.Z1, w1, ctx->R1, w1), 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
       GemmArgs a = mk(Mp, w1, Pl, ctx->Gt, Mp, ctx->X1, w1, acc + y.acc_GX, w1, 1.0, 1);
-      a.splits = pick_splits(Mp, w1, Pl);
+      a.splits = pick_splits(ctx, Mp, w1, Pl);
       RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
       ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 24);
       HIPCHK(xbar_finish(ctx->st, ctx->R1, ctx->X1, Pl, P(ctx, y.off_ls), Din, D, y.d.mean_kind, y.meanW, y.mbar,
@@ -500,6 +533,10 @@ int dgp_create(int device, void* hip_stream, dgp_ctx** out) {
       hipMalloc(reinterpret_cast<void**>(&ctx->info), sizeof(int)) != hipSuccess) {
     delete ctx;
     return DGP_ERR_HIP;
+  }
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
   }
   (void)hipMemset(ctx->info, 0, sizeof(int));
   (void)hipMemset(ctx->scal, 0, 4 * sizeof(double));

@@ -137,20 +137,37 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   constexpr int FM = Cfg::FM, FN = Cfg::FN;
   __shared__ __attribute__((aligned(16))) double smem[2 * (Cfg::AS_SZ + Cfg::BS_SZ)];
 
-  // ---- tile coordinates: XCD-aware remap so that one XCD's L2 sees a contiguous run of tiles ----
-  const long tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
-  const long ntile = tiles_n * tiles_m;
-  long bid = blockIdx.x;
-  {
-    const long q = ntile / 8, r = ntile % 8, xcd = bid % 8, idx = bid / 8;
+  // ---- tile coordinates (32-bit index arithmetic: a 64-bit divide is hundreds of instructions per workgroup) ----
+  const unsigned tiles_n = (unsigned)((g.N + BN - 1) / BN), tiles_m = (unsigned)((g.M + BM - 1) / BM);
+  const unsigned ntile = tiles_n * tiles_m;
+  unsigned bid, bz, sp;
+  if (g.splits > 1 && g.splits % 8 == 0) {
+    // Reduction over K split into chunks.  All (tile, batch) members that stream the SAME chunk of rows are
+    // placed on ONE XCD, back to back, so that the chunk is fetched from HBM once and re-read from that XCD's
+    // L2 (blocks are dealt round-robin over the 8 XCDs in launch order, x fastest: placement is a speed
+    // matter only).  Without this the Gram kernels had a 0 % L2 hit rate and were HBM-bound.
+    const unsigned members = ntile * (unsigned)g.batch;
+    const unsigned L = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = L & 7u, j = L >> 3;
+    const unsigned grp = j / members, mem = j - grp * members;
+    sp = grp * 8u + xcd;
+    bz = mem / ntile;
+    bid = mem - bz * ntile;
+  } else {
+    // one XCD's L2 sees a contiguous run of tiles
+    bid = blockIdx.x;
+    const unsigned q = ntile / 8u, r = ntile % 8u, xcd = bid % 8u, idx = bid / 8u;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any ntile
+    const unsigned z = blockIdx.y;
+    // batch fastest: the batches of one K-split read the same rows of the streamed operands back to back
+    bz = z % (unsigned)g.batch;
+    sp = z / (unsigned)g.batch;
   }
-  const long tm = bid / tiles_n, tn = bid % tiles_n;     // column tiles fastest: neighbours share A rows
+  const unsigned tm_u = bid / tiles_n, tn_u = bid - tm_u * tiles_n;   // column tiles fastest: neighbours share A rows
+  const long tm = tm_u, tn = tn_u;
   const long m0 = tm * BM, n0 = tn * BN;
-  const int z = blockIdx.y;
-  const int bz = z / g.splits, sp = z % g.splits;
 
-  const long nloc0 = (g.tri != TRI_NONE && g.triblk > 0) ? (n0 % g.triblk) : n0;
+  const long nloc0 = (g.tri != TRI_NONE && g.triblk > 0) ? (long)((unsigned)n0 % (unsigned)g.triblk) : n0;
   const bool tri_ok = (g.tri != TRI_NONE) && (g.triblk % BN == 0 || g.N <= g.triblk);
   if (g.tri == TRI_OUT_LOWER && tri_ok && (m0 + BM - 1) < nloc0) return;     // tile strictly above the diagonal
 
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   long kblen = g.K, nkb = 1, klo = 0, khi = g.K;
   if ((g.tri == TRI_B_UPPER || g.tri == TRI_B_LOWER) && tri_ok) {
     kblen = (g.K > g.triblk) ? g.triblk : g.K;
-    nkb = g.K / kblen;
+    nkb = (long)((unsigned)g.K / (unsigned)kblen);
     if (g.tri == TRI_B_UPPER) { khi = nloc0 + BN; if (khi > kblen) khi = kblen; }
     else { klo = (nloc0 / BK) * BK; khi = kblen; }
   } else if (g.splits > 1) {
@@ -296,7 +313,10 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     const double* ps = nullptr;
     long s_pass = 0, s_kstride = 0;
     if constexpr (SCALED) {
-      ps = TA ? g.ascale + (klo + a_tr) * g.as_ld + bz : g.ascale + (m0 + a_tr) * g.as_ld;
+      // transposed A: a tile row is one k (point) and is loaded by a single wave (A_TPR == 64), so its scale is
+      // wave-uniform: address it through the scalar wave index and hipcc emits scalar (s_load) fetches
+      const int a_tr_s = (TA && Cfg::A_TPR == 64) ? wave : a_tr;
+      ps = TA ? g.ascale + (klo + a_tr_s) * g.as_ld + bz : g.ascale + (m0 + a_tr) * g.as_ld;
       s_pass = (long)Cfg::A_RPP * g.as_ld;
       s_kstride = TA ? g.as_ld : 0;
     }

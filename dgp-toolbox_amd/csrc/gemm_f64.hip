@@ -7,10 +7,13 @@ template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int 
 static hipError_t launch(hipStream_t st, GemmArgs a) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.batch <= 0) return hipSuccess;
   if (a.splits > 1) {   // ksplit must be a multiple of BK so that split boundaries coincide with k-tiles
+    const bool grouped = a.splits % 8 == 0;
+    while ((long)a.batch * a.splits > 65528 && a.splits > 8) a.splits = ((a.splits / 2 + 7) / 8) * 8;   // grid.y limit
     long per = (a.K + a.splits - 1) / a.splits;
     per = ((per + BK - 1) / BK) * BK;
     a.ksplit = per;
     a.splits = (int)((a.K + per - 1) / per);
+    if (grouped) a.splits = ((a.splits + 7) / 8) * 8;   // keep whole XCD groups (empty trailing splits exit at once)
   }
   if (a.splits < 1) a.splits = 1;
   const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
