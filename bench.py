@@ -143,6 +143,13 @@ def main():
         mf = prof["mfma_contractions"]
         achieved = mf["alg_flops"] / (mf["ms"] * 1e-3) / 1e12 if mf["ms"] > 0 else 0.0
         name, cus, mem = ctx.device_info()
+        traffic = None          # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if world == 1 and os.path.exists(tpath) and (args.N, args.M, args.S) == (100_000, 256, 10):
+            try:
+                traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
         out = {
             "metric": "ELBO iterations/sec (2-layer DGP, N=100k, M=256) at 1/2/4/8 GPUs; fp64 ELBO match",
             "value": it_s, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -153,7 +160,7 @@ def main():
                        "N": args.N, "D": args.D, "M": args.M, "S": args.S, "num_units": num_units,
                        "parallelism": f"data points sharded over {world} GPU(s), one all-reduce per iteration"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "dgp::gemm_f64_kernel (all point contractions, rank 0)",
                          "kernel_ms_per_step": mf["ms"] / args.steps, "launches_per_step": mf["launches"] / args.steps,
                          "alg_flops_per_step_rank0": mf["alg_flops"] / args.steps,

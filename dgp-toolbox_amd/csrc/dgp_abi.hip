@@ -446,7 +446,8 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     {  // dC = sum_d 2 vbar_d .* (C S'_d)      (A operand scaled on the fly; K = D*Mp re-reads C per block)
       GemmArgs a = mk(Pl, Mp, DM, y.Ct, Mp, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);
       a.ascale = y.vbar; a.as_ld = D; a.a_kblk = Mp; a.ascale_mode = 1;
-      RET(GX(ctx, 0, GEMM_NN, a, 2.0 * tri1 * D, (double)Pl * Mp * 16));
+      // algorithmic count: the D triangular products W_d t_d of SURVEY App. C (the dense S' form executes 2x that)
+      RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 16));
     }
     {
       ProfScope ps(ctx, 1, 0, (double)Pl * Mp * 16);

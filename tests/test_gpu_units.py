@@ -34,6 +34,18 @@ def test_gemm_matches_numpy(ctx, op, shape):
     assert _rel(C1, C0 + 0.5 * ref) < 1e-13
 
 
+@pytest.mark.parametrize("shape", [(256, 128, 20003), (128, 64, 4099), (384, 192, 1000)])
+def test_gemm_reduction_over_points_interior_plus_tails(ctx, shape):
+    """TN with M % 128 == 0, N % 64 == 0 and K not a multiple of 16: FAST interior kernel + generic K tail,
+    with and without XCD-grouped split-K (splits multiple of 8)."""
+    M, N, K = shape
+    rng = np.random.default_rng(K)
+    A = rng.standard_normal((K, M)); B = rng.standard_normal((K, N)); C0 = rng.standard_normal((M, N))
+    for splits in (1, 8, 24):
+        C = ctx.dev_gemm("TN", A, B, C0=C0, beta=1, splits=splits)
+        assert _rel(C, C0 + A.T @ B) < 1e-12, splits
+
+
 def test_gemm_split_k_atomic_accumulation(ctx):
     rng = np.random.default_rng(5)
     A = rng.standard_normal((20000, 96))
