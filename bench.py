@@ -86,8 +86,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        backend = os.environ.get("DGP_BENCH_BACKEND", "nccl")       # "gloo": rehearsal of the N>1 path on fewer GPUs
+        ndev = max(1, torch.cuda.device_count())
+        local_rank = local_rank % ndev
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from dgp_dace.gpflow_compat import RBF, Gaussian
     from dgp_dace.models.dgp import DGP
@@ -132,10 +138,7 @@ def main():
     ctx.prof_enable(False)
     model._device_newer = True
     if dist:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = model._dist.all_reduce_max(dt, local_rank)
     elbo_last = ctx.last_elbo()
 
     if rank == 0:

@@ -91,7 +91,7 @@ class DGP_Base:
         """Create the device context on first use; raises if the HIP library / GPU is missing."""
         if self._ctx is None:
             self._dist = parallel.current()
-            dev = self._device if self._device is not None else (self._dist.local_rank if self._dist else 0)
+            dev = self._device if self._device is not None else (self._dist.local_device() if self._dist else 0)
             stream = self._dist.stream_handle(dev) if self._dist else None
             self._ctx = _native.Context(dev, stream)
         return self._ctx

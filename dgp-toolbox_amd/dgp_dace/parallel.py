@@ -24,8 +24,14 @@ class Dist:
         self.torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.local_rank = int(os.environ.get("LOCAL_RANK", self.rank))
-        self.on_gpu = dist.get_backend() == "nccl"
+        # device tensors whenever a GPU is visible: RCCL ("nccl") in production; gloo also reduces device tensors
+        # (staged through the host), which lets two ranks rehearse the whole path on ONE GPU in tests
+        self.on_gpu = dist.get_backend() == "nccl" or (torch.cuda.is_available() and os.environ.get("DGP_DIST_DEVICE", "1") == "1")
         self._stream = None
+
+    def local_device(self):
+        n = self.torch.cuda.device_count() if self.on_gpu else 1
+        return self.local_rank % max(1, n)
 
     def shard(self, N):
         return shard_bounds(N, self.rank, self.world)
@@ -54,6 +60,11 @@ class Dist:
     def all_reduce_scalar(self, v, dev=0):
         t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=(f"cuda:{dev}" if self.on_gpu else "cpu"))
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def all_reduce_max(self, v, dev=0):
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=(f"cuda:{dev}" if self.on_gpu else "cpu"))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def barrier(self):

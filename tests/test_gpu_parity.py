@@ -189,3 +189,52 @@ def test_medium_size_against_oracle():
         for k in ("Z", "lengthscales", "variance", "q_mu"):
             ref = G["layers"][i][k]
             assert np.abs(Gp[(i, k)] - ref).max() < 1e-6 * max(1.0, np.abs(ref).max()), (i, k)
+
+
+DIST_WORKER = r'''
+import os, sys
+sys.path[:0] = [os.path.join(ROOT, "dgp-toolbox_amd"), os.path.join(ROOT, "tests")]
+os.environ["LOCAL_RANK"] = str(RANK)
+import numpy as np, torch, torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % PORT, rank=RANK, world_size=2)
+from helpers import load, product_from_golden, split_flat
+g = load("case_B_nonwhite")
+m = product_from_golden(g, seed=21)            # every rank builds the same model; _sync_data keeps its shard only
+assert m._engine() is not None and m._dist is not None and m._dist.world == 2 and m._dist.on_gpu
+ctx = m._grad_step(m.data)                      # shard -> partial sums on the GPU -> all-reduce -> finish
+elbo = ctx.last_elbo()
+grad = ctx.grad_get()
+ctx.adam_step(0.01, 0.9, 0.999, 1e-7, m._trainable_flags())
+m._device_newer = True
+e2 = m.ELBO()                                   # forward-only path with the scalar all-reduce
+if RANK == 0:
+    np.savez(OUT, elbo=elbo, grad=grad, e2=e2, z=m.layers[0].feature.Z.numpy())
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
+    """The N>1 path end to end (sharded upload, device partial-sum buffer bound to a torch tensor, stream sharing,
+    all-reduce, replicated finish + Adam) with 2 ranks sharing this GPU over gloo; RCCL itself is the only piece
+    not exercised.  Must equal the single-process result (normals are keyed by the global point index)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29600 + (os.getpid() % 2000)
+    out = str(tmp_path / "dist.npz")
+    procs = []
+    for rank in (0, 1):
+        code = f"ROOT={root!r}\nPORT={port}\nRANK={rank}\nOUT={out!r}\n" + DIST_WORKER
+        procs.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    d = np.load(out)
+    g = load("case_B_nonwhite")
+    m = product_from_golden(g, seed=21)
+    ctx = m._grad_step(m.data)
+    assert abs(ctx.last_elbo() - d["elbo"]) < 1e-10 * abs(d["elbo"])
+    _close(ctx.grad_get(), d["grad"], rtol=1e-9, atol=1e-9)
+    ctx.adam_step(0.01, 0.9, 0.999, 1e-7, m._trainable_flags())
+    m._device_newer = True
+    assert abs(m.ELBO() - d["e2"]) < 1e-9 * abs(d["e2"])
+    _close(m.layers[0].feature.Z.numpy(), d["z"], rtol=1e-10, atol=1e-12)
