@@ -52,6 +52,9 @@ struct GemmArgs {
   int beta;          // 0: overwrite, 1: accumulate (non-atomic; ignored when splits > 1)
   int tri;
   long triblk;
+  // TRI_OUT_LOWER launches: number of output tiles that survive the skip when the grid is COMPACT (only those
+  // tiles are launched: early-exit workgroups were measured to cost as much as running ones); 0 = full grid
+  int active_tiles = 0;
   // optional row scaling of the physical A tile (fused elementwise work, no extra HBM pass):
   //   ascale_mode 1 (A not transposed): A[m][k] = ascale[m*as_ld + k / a_kblk] * Aphys[m][k % a_kblk]
   //                                     (K = nblk * a_kblk re-reads the same physical columns per block)
@@ -139,15 +142,22 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 
   // ---- tile coordinates (32-bit index arithmetic: a 64-bit divide is hundreds of instructions per workgroup) ----
   const unsigned tiles_n = (unsigned)((g.N + BN - 1) / BN), tiles_m = (unsigned)((g.M + BM - 1) / BM);
-  const unsigned ntile = tiles_n * tiles_m;
+  const unsigned ntile = g.active_tiles > 0 ? (unsigned)g.active_tiles : tiles_n * tiles_m;
+  const bool grouped = g.splits > 1 && g.splits % 8 == 0;
+  // PERSISTENT over tiles: the host may launch fewer workgroups (gridDim.x) than tiles; each workgroup then walks
+  // tiles lin = blockIdx.x, + gridDim.x, ...  Launching a workgroup of this kernel costs ~10 us of slot time
+  // (measured: early-exit workgroups were as expensive as running ones), which dominated the short-K products.
+  // Every wave of the workgroup takes the same trip count, so the barriers inside stay uniform.
+  const unsigned nlin = grouped ? gridDim.x : ntile;
+  for (unsigned lin = blockIdx.x; lin < nlin; lin += gridDim.x) {
   unsigned bid, bz, sp;
-  if (g.splits > 1 && g.splits % 8 == 0) {
+  if (grouped) {
     // Reduction over K split into chunks.  All (tile, batch) members that stream the SAME chunk of rows are
     // placed on ONE XCD, back to back, so that the chunk is fetched from HBM once and re-read from that XCD's
     // L2 (blocks are dealt round-robin over the 8 XCDs in launch order, x fastest: placement is a speed
     // matter only).  Without this the Gram kernels had a 0 % L2 hit rate and were HBM-bound.
     const unsigned members = ntile * (unsigned)g.batch;
-    const unsigned L = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned L = blockIdx.y * gridDim.x + lin;
     const unsigned xcd = L & 7u, j = L >> 3;
     const unsigned grp = j / members, mem = j - grp * members;
     sp = grp * 8u + xcd;
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     bid = mem - bz * ntile;
   } else {
     // one XCD's L2 sees a contiguous run of tiles
-    bid = blockIdx.x;
+    bid = lin;
     const unsigned q = ntile / 8u, r = ntile % 8u, xcd = bid % 8u, idx = bid / 8u;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any ntile
     const unsigned z = blockIdx.y;
@@ -163,13 +173,26 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     bz = z % (unsigned)g.batch;
     sp = z / (unsigned)g.batch;
   }
-  const unsigned tm_u = bid / tiles_n, tn_u = bid - tm_u * tiles_n;   // column tiles fastest: neighbours share A rows
+  unsigned tm_u, tn_u;
+  if (g.active_tiles > 0) {
+    // compact grid: bid enumerates only the tiles with (m0 + BM - 1) >= (n0 mod triblk); find the bid-th one
+    unsigned cnt = 0;
+    tm_u = tn_u = 0;
+    for (unsigned t = 0; t < tiles_n * tiles_m; ++t) {
+      const unsigned a = t / tiles_n, b = t - a * tiles_n;
+      const bool act = (a * BM + BM - 1) >= ((b * BN) % (unsigned)g.triblk);
+      if (act) { if (cnt == bid) { tm_u = a; tn_u = b; } ++cnt; }
+    }
+  } else {
+    tm_u = bid / tiles_n;
+    tn_u = bid - tm_u * tiles_n;   // column tiles fastest: neighbours share A rows
+  }
   const long tm = tm_u, tn = tn_u;
   const long m0 = tm * BM, n0 = tn * BN;
 
   const long nloc0 = (g.tri != TRI_NONE && g.triblk > 0) ? (long)((unsigned)n0 % (unsigned)g.triblk) : n0;
   const bool tri_ok = (g.tri != TRI_NONE) && (g.triblk % BN == 0 || g.N <= g.triblk);
-  if (g.tri == TRI_OUT_LOWER && tri_ok && (m0 + BM - 1) < nloc0) return;     // tile strictly above the diagonal
+  if (g.tri == TRI_OUT_LOWER && tri_ok && (m0 + BM - 1) < nloc0) continue;   // tile strictly above the diagonal
 
   const double* __restrict__ A = g.A + (long)bz * g.sA;
   const double* __restrict__ B = g.B + (long)bz * g.sB;
@@ -185,7 +208,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   } else if (g.splits > 1) {
     klo = (long)sp * g.ksplit;
     khi = klo + g.ksplit; if (khi > g.K) khi = g.K;
-    if (klo >= khi) return;
+    if (klo >= khi) continue;
   }
   const long ktiles_per_blk = (khi - klo + BK - 1) / BK;
   const long ktiles = ktiles_per_blk * nkb;
@@ -391,7 +414,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       const long row = m0 + (long)(i * WR + wr) * 16 + 4 * (li >> 2) + lk;
       if ((li & 3) == 0 && row < g.M) rs[row] = q;
     }
-    if (g.epi == 1) return;
+    if (g.epi == 1) continue;
   }
   const bool atomic = g.splits > 1;
 #pragma unroll
@@ -413,6 +436,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       }
     }
   }
+  }   // persistent tile loop
 }
 
 // Host-side dispatcher (defined in gemm_f64.hip)

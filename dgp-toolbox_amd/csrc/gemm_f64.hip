@@ -16,8 +16,22 @@ static hipError_t launch(hipStream_t st, GemmArgs a) {
     if (grouped) a.splits = ((a.splits + 7) / 8) * 8;   // keep whole XCD groups (empty trailing splits exit at once)
   }
   if (a.splits < 1) a.splits = 1;
-  const long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  dim3 grid((unsigned)tiles, (unsigned)(a.batch * a.splits), 1);
+  long tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  a.active_tiles = 0;
+  if (a.tri == TRI_OUT_LOWER && a.triblk > 0 && (a.triblk % BN == 0 || a.N <= a.triblk) && tiles <= 4096) {
+    long act = 0;                                        // launch only the tiles on or below the diagonal
+    for (long m0 = 0; m0 < a.M; m0 += BM)
+      for (long n0 = 0; n0 < a.N; n0 += BN)
+        if (m0 + BM - 1 >= n0 % a.triblk) ++act;
+    if (act < tiles) { a.active_tiles = (int)act; tiles = act; }
+  }
+  // persistent grid: at most 8*255 workgroups walk the tiles (a multiple of 8 keeps a workgroup's tiles on its
+  // XCD's contiguous run; 255 is odd so that successive tiles of one workgroup cycle through the column tiles).
+  // XCD-grouped split-K launches keep one workgroup per (tile, batch, split).
+  const bool grouped = a.splits > 1 && a.splits % 8 == 0;
+  long gx = tiles;
+  if (!grouped && gx > 2040) gx = 2040;
+  dim3 grid((unsigned)gx, (unsigned)(a.batch * a.splits), 1);
   hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, VA, VB, FAST, SCALED>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }

@@ -43,53 +43,53 @@ hipError_t rbf_kuu(hipStream_t st, const double* Z, const double* var, const dou
 // triangular_solve on Kuu (layers.py:231,245-247) and GPflow's chol(-2 nat2), its inverse and chol(S).
 constexpr int LEAF = 64;
 
-__global__ __launch_bounds__(256) void leaf_potrf_inv_kernel(double* __restrict__ Aall, double* __restrict__ Xall, int ld,
-                                                             long stride, int off, int n, int do_chol,
-                                                             int* __restrict__ info) {
+// One wave per matrix: thread i owns row i; the matrix lives in LDS, so a barrier is a single-wave s_barrier.
+__global__ __launch_bounds__(64) void leaf_potrf_inv_kernel(double* __restrict__ Aall, double* __restrict__ Xall, int ld,
+                                                            long stride, int off, int n, int do_chol,
+                                                            int* __restrict__ info) {
   __shared__ double Ls[LEAF][LEAF + 1];
   __shared__ double Xs[LEAF][LEAF + 1];
   double* A = Aall + (long)blockIdx.x * stride + (long)off * ld + off;
   double* X = Xall + (long)blockIdx.x * stride + (long)off * ld + off;
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < n * n; idx += 256) {
-    const int r = idx / n, c = idx % n;
-    Ls[r][c] = (c <= r) ? A[(long)r * ld + c] : 0.0;
-  }
+  const int i = threadIdx.x;
+  if (i < n)
+    for (int c = 0; c < n; ++c) Ls[i][c] = (c <= i) ? A[(long)i * ld + c] : 0.0;
   __syncthreads();
   if (do_chol) {
+    // left-looking by columns: column c needs the finished columns 0..c-1 only -> one barrier per column
     for (int c = 0; c < n; ++c) {
-      if (tid == 0) {
-        const double d = Ls[c][c];
-        if (!(d > 0.0)) { atomicOr(info, 1); Ls[c][c] = nan(""); }
-        else Ls[c][c] = sqrt(d);
+      double v = 0.0;
+      if (i >= c && i < n) {
+        v = Ls[i][c];
+        for (int k = 0; k < c; ++k) v -= Ls[i][k] * Ls[c][k];
       }
-      __syncthreads();
-      if (tid > c && tid < n) Ls[tid][c] /= Ls[c][c];
-      __syncthreads();
-      for (int idx = tid; idx < n * n; idx += 256) {
-        const int i = idx / n, k = idx % n;
-        if (k > c && i >= k) Ls[i][k] -= Ls[i][c] * Ls[k][c];
+      const double piv = __shfl(v, c);                 // pivot of this column (lane c)
+      if (i == c) {
+        if (!(piv > 0.0)) atomicOr(info, 1);
+        Ls[c][c] = (piv > 0.0) ? sqrt(piv) : nan("");
+      } else if (i > c && i < n) {
+        Ls[i][c] = v / ((piv > 0.0) ? sqrt(piv) : nan(""));
       }
       __syncthreads();
     }
   }
   // inverse: thread j owns column j (forward substitution, everything in LDS)
-  if (tid < n) {
-    const int j = tid;
-    for (int i = 0; i < j; ++i) Xs[i][j] = 0.0;
+  if (i < n) {
+    const int j = i;
+    for (int r = 0; r < j; ++r) Xs[r][j] = 0.0;
     Xs[j][j] = 1.0 / Ls[j][j];
-    for (int i = j + 1; i < n; ++i) {
+    for (int r = j + 1; r < n; ++r) {
       double s = 0.0;
-      for (int k = j; k < i; ++k) s += Ls[i][k] * Xs[k][j];
-      Xs[i][j] = -s / Ls[i][i];
+      for (int k = j; k < r; ++k) s += Ls[r][k] * Xs[k][j];
+      Xs[r][j] = -s / Ls[r][r];
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < n * n; idx += 256) {
-    const int r = idx / n, c = idx % n;
-    if (do_chol) A[(long)r * ld + c] = Ls[r][c];
-    X[(long)r * ld + c] = Xs[r][c];
-  }
+  if (i < n)
+    for (int c = 0; c < n; ++c) {
+      if (do_chol) A[(long)i * ld + c] = Ls[i][c];
+      X[(long)i * ld + c] = Xs[i][c];
+    }
 }
 
 __global__ void zero_block_kernel(double* __restrict__ Aall, int ld, long stride, int r0, int c0, int nr, int nc) {
@@ -113,7 +113,7 @@ static hipError_t potrf_inv_rec(hipStream_t st, double* A, double* X, double* tm
                                 int n, int do_chol, int* info) {
   hipError_t e;
   if (n <= LEAF) {
-    hipLaunchKernelGGL(leaf_potrf_inv_kernel, dim3(batch), dim3(256), 0, st, A, X, ld, stride, off, n, do_chol, info);
+    hipLaunchKernelGGL(leaf_potrf_inv_kernel, dim3(batch), dim3(64), 0, st, A, X, ld, stride, off, n, do_chol, info);
     return hipGetLastError();
   }
   int n1 = ((n / 2 + 15) / 16) * 16;
@@ -317,31 +317,34 @@ __device__ __forceinline__ double block_sum_1024(double v, double* sh) {
   return t;    // valid on thread 0
 }
 
-__global__ __launch_bounds__(1024) void layer_kl_kernel(const double* __restrict__ Wcat, const double* __restrict__ u,
-                                                        const double* __restrict__ Lq, const double* __restrict__ Lu,
-                                                        int M, int Mp, int D, int white, double* __restrict__ out) {
-  __shared__ double sh[16];
+__global__ __launch_bounds__(256) void layer_kl_kernel(const double* __restrict__ Wcat, const double* __restrict__ u,
+                                                       const double* __restrict__ Lq, const double* __restrict__ Lu,
+                                                       int M, int Mp, int D, int white, double* __restrict__ out) {
+  __shared__ double sh[4];
   double acc = 0.0;
-  const long nW = (long)Mp * D * Mp;
-  for (long idx = threadIdx.x; idx < nW; idx += blockDim.x) {
+  const long nW = (long)Mp * D * Mp, gstride = (long)gridDim.x * blockDim.x, g0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long idx = g0; idx < nW; idx += gstride) {
     const int k = (int)(idx / ((long)D * Mp)), n = (int)(idx % Mp);
     if (k < M && n < M) { const double w = Wcat[idx]; acc += 0.5 * w * w; }
   }
-  for (long idx = threadIdx.x; idx < (long)M * D; idx += blockDim.x) { const double x = u[idx]; acc += 0.5 * x * x; }
-  for (long idx = threadIdx.x; idx < (long)D * M; idx += blockDim.x) {
+  for (long idx = g0; idx < (long)M * D; idx += gstride) { const double x = u[idx]; acc += 0.5 * x * x; }
+  for (long idx = g0; idx < (long)D * M; idx += gstride) {
     const int d = (int)(idx / M), i = (int)(idx % M);
     const double q = Lq[((long)d * Mp + i) * Mp + i];
     acc -= 0.5 * log(q * q);
   }
   if (!white)
-    for (int i = threadIdx.x; i < M; i += blockDim.x) acc += (double)D * log(Lu[(long)i * Mp + i]);
-  const double t = block_sum_1024(acc, sh);
-  if (threadIdx.x == 0) out[0] += t - 0.5 * (double)D * (double)M;
+    for (long i = g0; i < M; i += gstride) acc += (double)D * log(Lu[i * Mp + i]);
+  if (g0 == 0) acc -= 0.5 * (double)D * (double)M;
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
 hipError_t layer_kl(hipStream_t st, const double* Wcat, const double* u, const double* Lq, const double* Lu, int M,
                     int Mp, int D, int white, double* kl_out) {
-  hipLaunchKernelGGL(layer_kl_kernel, dim3(1), dim3(1024), 0, st, Wcat, u, Lq, Lu, M, Mp, D, white, kl_out);
+  hipLaunchKernelGGL(layer_kl_kernel, dim3(64), dim3(256), 0, st, Wcat, u, Lq, Lu, M, Mp, D, white, kl_out);
   LAUNCH_CHECK();
 }
 

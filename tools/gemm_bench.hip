@@ -46,6 +46,27 @@ double run(const char* name, long M, long N, long K, int splits, int tri, long t
   return ms;
 }
 
+template <bool SC>
+void run_g(const char* name, long P, long Mp, int D, int splits, int tri, double* Ct, double* vbar, double* G, long Ncols = 0) {
+  GemmArgs a;
+  a.A = Ct; a.B = Ct; a.C = G; a.lda = Mp; a.ldb = Mp; a.ldc = Mp; a.M = Mp; a.N = Ncols ? Ncols : Mp; a.K = P;
+  a.sA = 0; a.sB = 0; a.sC = Mp * Mp; a.batch = D; a.splits = splits; a.alpha = 1.0; a.beta = 1; a.tri = tri; a.triblk = Mp;
+  if (SC) { a.ascale = vbar; a.as_ld = D; a.ascale_mode = 2; }
+  long per = (P + splits - 1) / splits; per = ((per + 15) / 16) * 16; a.ksplit = per; a.splits = (int)((P + per - 1) / per);
+  if (splits % 8 == 0) a.splits = ((a.splits + 7) / 8) * 8;
+  const long tiles = ((Mp + 127) / 128) * ((a.N + 63) / 64);
+  dim3 grid((unsigned)tiles, (unsigned)(a.batch * a.splits));
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((gemm_f64_kernel<true, false, 128, 64, 16, 2, 2, 2, 2, true, SC>), grid, dim3(256), 0, 0, a);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((gemm_f64_kernel<true, false, 128, 64, 16, 2, 2, 2, 2, true, SC>), grid, dim3(256), 0, 0, a);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+  const double frac = tri ? 0.75 : 1.0;
+  printf("%-56s splits=%4d  %8.3f ms  executed %6.1f TF\n", name, a.splits, ms, 2.0 * P * Mp * a.N * D * frac / ms / 1e9);
+}
+
 int main(int argc, char** argv) {
   // the FAST kernels carry no bounds checks: the harness must only hand them interior shapes (the library's
   // host dispatcher guarantees this; here P is rounded to a multiple of the largest tile height)
@@ -65,11 +86,19 @@ int main(int argc, char** argv) {
 #define CB(BM, BN, BK, WR, WC) run<false, false, BM, BN, BK, WR, WC, true>("NN  Cbar=C'*Scat dense K=D*Mp", P, Mp, DM, 1, 0, 0, A, B, C, DM, Mp, Mp, 1.0)
 #define TT(BM, BN, BK, WR, WC) run<false, false, BM, BN, BK, WR, WC, true>("NN  Tt=Ct*Wcat tri K=Mp", P, DM, Mp, 1, TRI_B_LOWER, Mp, A, B, C, Mp, DM, DM, 0.5 + 0.5 * BN / Mp)
 #define GR(BM, BN, BK, WR, WC) run<true, false, BM, BN, BK, WR, WC, true>("TN  G=Ct^T*Ct (K=P) splits", Mp, DM, P, 48, TRI_OUT_LOWER, Mp, B + Mp * DM, A, C, Mp, DM, DM, 0.75)
-  run<true, false, 128, 64, 16, 2, 2, true>("TN  G batch-like N=Mp dense  s=32", Mp, Mp, P, 32, 0, 0, B + Mp * DM, A, C, Mp, DM, Mp, 1.0);
-  run<true, false, 128, 64, 16, 2, 2, true>("TN  G batch-like N=Mp lower  s=32", Mp, Mp, P, 32, TRI_OUT_LOWER, Mp, B + Mp * DM, A, C, Mp, DM, Mp, 0.75);
-  run<true, false, 128, 64, 16, 2, 2, true>("TN  G N=D*Mp dense  s=48", Mp, DM, P, 48, 0, 0, B + Mp * DM, A, C, Mp, DM, DM, 1.0);
-  run<true, false, 128, 64, 16, 2, 2, true>("TN  G N=D*Mp lower  s=48", Mp, DM, P, 48, TRI_OUT_LOWER, Mp, B + Mp * DM, A, C, Mp, DM, DM, 0.75);
-  run<true, false, 128, 64, 16, 2, 2, true>("TN  G N=D*Mp dense  s=64", Mp, DM, P, 64, 0, 0, B + Mp * DM, A, C, Mp, DM, DM, 1.0);
-  run<true, false, 128, 64, 16, 2, 2, true>("TN  G N=D*Mp dense  s=16", Mp, DM, P, 16, 0, 0, B + Mp * DM, A, C, Mp, DM, DM, 1.0);
+  {
+    double* vb; hipMalloc(&vb, P * D * 8); hipMemset(vb, 0, P * D * 8);
+    double* Ct = B + Mp * DM;   // [P x Mp]
+    run_g<true>("G production: batch 8, scaled, lower, grouped", P, Mp, (int)D, 248, TRI_OUT_LOWER, Ct, vb, C);
+    run_g<false>("G unscaled,  batch 8, lower, grouped", P, Mp, (int)D, 248, TRI_OUT_LOWER, Ct, vb, C);
+    run_g<false>("G unscaled,  batch 8, dense, grouped", P, Mp, (int)D, 248, 0, Ct, vb, C);
+    run_g<false>("G unscaled,  batch 8, dense, ungrouped(s=47)", P, Mp, (int)D, 47, 0, Ct, vb, C);
+    run_g<false>("G unscaled,  batch 8, dense, grouped s=1000", P, Mp, (int)D, 1000, 0, Ct, vb, C);
+    run_g<false>("G unscaled,  batch 1, dense, grouped", P, Mp, 1, 248, 0, Ct, vb, C);
+    run_g<true>("G scaled,    batch 8, dense, grouped", P, Mp, (int)D, 248, 0, Ct, vb, C);
+    run_g<false>("G unscaled, batch 8, dense N=192 (6 of 8 tiles)", P, Mp, (int)D, 248, 0, Ct, vb, C, 192);
+    run_g<false>("G unscaled, batch 8, dense N=128 (4 of 8 tiles)", P, Mp, (int)D, 248, 0, Ct, vb, C, 128);
+    run_g<false>("G unscaled, batch 8, dense N=64  (2 of 8 tiles)", P, Mp, (int)D, 248, 0, Ct, vb, C, 64);
+  }
   return 0;
 }
