@@ -66,6 +66,10 @@ struct GemmArgs {
   int epi = 0;
   double* rowsq = nullptr;
   long rowsq_ld = 0;
+  // optional rank-R update in the epilogue: C += rowf[M x R] * colf[N x R]^T  (fuses dC += mbar u^T)
+  const double* rowf = nullptr;
+  const double* colf = nullptr;
+  int rank = 0;
   // optional second output C2 = (alpha * A B) .* E  (same shape / leading dimension as C; used for g = dK .* K)
   const double* emul = nullptr;
   double* C2 = nullptr;
@@ -427,7 +431,12 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
         const long col = n0 + (long)(j * WC + wc) * 16 + ((li + 4 * r) & 15);
         if (row < g.M && col < g.N) {
           double* p = C + row * g.ldc + col;
-          const double v = g.alpha * acc[i][j][r];
+          double v = g.alpha * acc[i][j][r];
+          if (g.rank > 0) {
+            const double* rf = g.rowf + row * g.rank;
+            const double* cf = g.colf + col * g.rank;
+            for (int q = 0; q < g.rank; ++q) v += rf[q] * cf[q];
+          }
           if (atomic) unsafeAtomicAdd(p, v);
           else if (g.beta) *p += v;
           else *p = v;

@@ -1,5 +1,6 @@
 // Host-side dispatch of the fp64 MFMA GEMM engine (see gemm_f64.h).
 #include "gemm_f64.h"
+#include <cstdlib>
 
 namespace dgp {
 
@@ -30,7 +31,9 @@ static hipError_t launch(hipStream_t st, GemmArgs a) {
   // XCD-grouped split-K launches keep one workgroup per (tile, batch, split).
   const bool grouped = a.splits > 1 && a.splits % 8 == 0;
   long gx = tiles;
-  if (!grouped && gx > 2040) gx = 2040;
+  static long gmax = 0;
+  if (gmax == 0) { const char* e = getenv("DGP_GEMM_GRID"); gmax = e ? atol(e) : 4088; if (gmax < 8) gmax = 8; }
+  if (!grouped && gx > gmax) gx = gmax;
   dim3 grid((unsigned)gx, (unsigned)(a.batch * a.splits), 1);
   hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, VA, VB, FAST, SCALED>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
@@ -98,6 +101,7 @@ static hipError_t dispatch(hipStream_t st, const GemmArgs& a) {
     r.A = TA ? a.A + Mf : a.A + Mf * a.lda;
     if (a.C) r.C = a.C + Mf * a.ldc;
     if (a.C2) { r.C2 = a.C2 + Mf * a.ldc; r.emul = a.emul + Mf * a.ldc; }
+    if (a.rank > 0) r.rowf = a.rowf + Mf * a.rank;
     if (a.rowsq) r.rowsq = a.rowsq + Mf;
     if (a.ascale_mode == 1) r.ascale = a.ascale + Mf * a.as_ld;
     if ((e = launch_generic<TA, TB>(st, r)) != hipSuccess) return e;
