@@ -55,6 +55,7 @@ struct GemmArgs {
   // TRI_OUT_LOWER launches: number of output tiles that survive the skip when the grid is COMPACT (only those
   // tiles are launched: early-exit workgroups were measured to cost as much as running ones); 0 = full grid
   int active_tiles = 0;
+  long tri_row0 = 0;   // absolute row of C's first row (set when the host launches a row strip of a larger product)
   // optional row scaling of the physical A tile (fused elementwise work, no extra HBM pass):
   //   ascale_mode 1 (A not transposed): A[m][k] = ascale[m*as_ld + k / a_kblk] * Aphys[m][k % a_kblk]
   //                                     (K = nblk * a_kblk re-reads the same physical columns per block)
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     tm_u = tn_u = 0;
     for (unsigned t = 0; t < tiles_n * tiles_m; ++t) {
       const unsigned a = t / tiles_n, b = t - a * tiles_n;
-      const bool act = (a * BM + BM - 1) >= ((b * BN) % (unsigned)g.triblk);
+      const bool act = ((unsigned)g.tri_row0 + a * BM + BM - 1) >= ((b * BN) % (unsigned)g.triblk);
       if (act) { if (cnt == bid) { tm_u = a; tn_u = b; } ++cnt; }
     }
   } else {
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 
   const long nloc0 = (g.tri != TRI_NONE && g.triblk > 0) ? (long)((unsigned)n0 % (unsigned)g.triblk) : n0;
   const bool tri_ok = (g.tri != TRI_NONE) && (g.triblk % BN == 0 || g.N <= g.triblk);
-  if (g.tri == TRI_OUT_LOWER && tri_ok && (m0 + BM - 1) < nloc0) continue;   // tile strictly above the diagonal
+  if (g.tri == TRI_OUT_LOWER && tri_ok && (g.tri_row0 + m0 + BM - 1) < nloc0) continue;   // tile strictly above the diagonal
 
   const double* __restrict__ A = g.A + (long)bz * g.sA;
   const double* __restrict__ B = g.B + (long)bz * g.sB;

@@ -23,7 +23,7 @@ static hipError_t launch(hipStream_t st, GemmArgs a) {
     long act = 0;                                        // launch only the tiles on or below the diagonal
     for (long m0 = 0; m0 < a.M; m0 += BM)
       for (long n0 = 0; n0 < a.N; n0 += BN)
-        if (m0 + BM - 1 >= n0 % a.triblk) ++act;
+        if (a.tri_row0 + m0 + BM - 1 >= n0 % a.triblk) ++act;
     if (act < tiles) { a.active_tiles = (int)act; tiles = act; }
   }
   // persistent grid: at most 8*255 workgroups walk the tiles (a multiple of 8 keeps a workgroup's tiles on its
@@ -98,6 +98,7 @@ static hipError_t dispatch(hipStream_t st, const GemmArgs& a) {
   if (Mf < a.M) {         // remaining rows, full K
     GemmArgs r = a;
     r.M = a.M - Mf;
+    r.tri_row0 = a.tri_row0 + Mf;
     r.A = TA ? a.A + Mf : a.A + Mf * a.lda;
     if (a.C) r.C = a.C + Mf * a.ldc;
     if (a.C2) { r.C2 = a.C2 + Mf * a.ldc; r.emul = a.emul + Mf * a.ldc; }

@@ -92,6 +92,15 @@ __global__ __launch_bounds__(64) void leaf_potrf_inv_kernel(double* __restrict__
     }
 }
 
+// batched strided block copy: dst[b][r][c] = src[b][r][c] for an nr x nc block (leading dimension ld, batch stride)
+__global__ void copy_block_kernel(const double* __restrict__ src, double* __restrict__ dst, int ld, long stride, int nr,
+                                  int nc) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)nr * nc) return;
+  const long o = (long)blockIdx.y * stride + (idx / nc) * ld + idx % nc;
+  dst[o] = src[o];
+}
+
 __global__ void zero_block_kernel(double* __restrict__ Aall, int ld, long stride, int r0, int c0, int nr, int nc) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)nr * nc) return;
@@ -133,9 +142,11 @@ static hipError_t potrf_inv_rec(hipStream_t st, double* A, double* X, double* tm
     // A22 -= L21 L21^T
     if ((e = sub_gemm(st, GEMM_NT, n2, n2, n1, T, T, A22, ld, stride, batch, -1.0, 1)) != hipSuccess) return e;
     // A21 <- L21 : copy T -> A21 as  A21 = T * I  is wasteful; use a strided 2D copy per batch
-    for (int b = 0; b < batch; ++b)
-      if ((e = hipMemcpy2DAsync(A21 + (long)b * stride, (size_t)ld * 8, T + (long)b * stride, (size_t)ld * 8, (size_t)n1 * 8, n2,
-                                hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+    {
+      const long nc = (long)n2 * n1;
+      hipLaunchKernelGGL(copy_block_kernel, dim3((unsigned)((nc + 255) / 256), batch), dim3(256), 0, st, T, A21, ld, stride, n2, n1);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
   }
   if ((e = potrf_inv_rec(st, A, X, tmp, ld, stride, batch, off + n1, n2, do_chol, info)) != hipSuccess) return e;
   // X21 = -X22 (L21 X11)

@@ -238,3 +238,46 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     m._device_newer = True
     assert abs(m.ELBO() - d["e2"]) < 1e-9 * abs(d["e2"])
     _close(m.layers[0].feature.Z.numpy(), d["z"], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("white", [False, True])
+def test_odd_sizes_padding_and_edge_tiles(white):
+    """M=150 (padded to 192: interior + edge tiles, 3 column tiles), D 5 -> 3 (PCA mean) -> 2 outputs, N=700:
+    ELBO, every gradient block and one natural-gradient step against the oracle with the same Philox normals."""
+    import dgp_oracle_torch as T
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    rng = np.random.default_rng(42)
+    N, D, M, S = 700, 5, 150, 3
+    X = rng.standard_normal((N, D)); Y = np.stack([np.sin(X[:, 0]), X[:, 1] * X[:, 2]], 1) + 0.1 * rng.standard_normal((N, 2))
+    Z = X[rng.permutation(N)[:M]].copy()
+    m = DGP(X, Y, Z, [RBF(1.3, 0.9 + 0.2 * rng.uniform(size=d)) for d in (5, 3)], [3], Gaussian(variance=0.3), white=white,
+            num_samples=S)
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(1.0, np.ones(d)) for d in (5, 3)], [3], lik_variance=0.3, white=white, num_samples=S)
+    for l, lo in zip(m.layers, mo.layers):
+        lo.kern.variance = float(l.kern.variance.numpy()); lo.kern.lengthscales = l.kern.lengthscales.numpy()
+        mu = 0.3 * rng.standard_normal(lo.q_mu.shape)
+        sq = np.tril(0.1 * rng.standard_normal(lo.q_sqrt.shape)) + 0.6 * np.eye(M)[None]
+        if not white:      # a well-conditioned q(u): the whitened draw mapped through chol(Kuu) (as in tests/golden)
+            lo.build_cholesky()
+            mu, sq = lo.Lu @ mu, np.tril(lo.Lu[None] @ sq)
+        l.q_mu.assign(mu); l.q_sqrt.assign(sq); lo.q_mu = mu; lo.q_sqrt = np.tril(sq)
+    ctx = m._sync_model()
+    m._sync_data(m.data)
+    ctx.grad_partial(S, 5, None)
+    elbo = ctx.grad_finish(want_elbo=True)
+    zs = O.draw_zs(mo, 5, S, N)
+    eo, G = T.elbo_and_grads(mo, zs)
+    assert abs(elbo - eo) < 1e-9 * abs(eo)
+    Gp = split_flat(m, ctx.grad_get())
+    for i in range(2):
+        for k in ("Z", "variance", "lengthscales", "q_mu", "q_sqrt"):
+            ref = G["layers"][i][k]
+            assert np.abs(Gp[(i, k)] - ref).max() < 1e-7 * max(1.0, np.abs(ref).max()), (i, k)
+    assert abs(Gp[("lik", "variance")] - G["lik_variance"]) < 1e-8 * max(1.0, abs(G["lik_variance"]))
+    ctx.natgrad_step(0.002, [True, True])
+    m._device_newer = True
+    for i, lo in enumerate(mo.layers):
+        mu_n, sq_n = O.natgrad_step(lo.q_mu, lo.q_sqrt, -G["layers"][i]["q_mu"], -G["layers"][i]["q_sqrt"], 0.002)
+        _close(m.layers[i].q_mu.numpy(), mu_n, rtol=1e-6, atol=1e-8)
+        _close(m.layers[i].q_sqrt.numpy(), sq_n, rtol=1e-6, atol=1e-8)
