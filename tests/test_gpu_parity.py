@@ -281,3 +281,57 @@ def test_odd_sizes_padding_and_edge_tiles(white):
         mu_n, sq_n = O.natgrad_step(lo.q_mu, lo.q_sqrt, -G["layers"][i]["q_mu"], -G["layers"][i]["q_sqrt"], 0.002)
         _close(m.layers[i].q_mu.numpy(), mu_n, rtol=1e-6, atol=1e-8)
         _close(m.layers[i].q_sqrt.numpy(), sq_n, rtol=1e-6, atol=1e-8)
+
+
+def test_full_size_properties_config2():
+    """BASELINE.json config 2 (N=100k, D=8, M=256, S=10, num_units=[8,8]) is too large for the oracle, so the
+    full-size path is checked through size-independent properties: (1) the ELBO does not depend on how the points
+    are chunked; (2) the hand-derived gradient is the derivative of the ELBO (central difference along a random
+    direction in all parameters, same Philox normals); (3) ELBO(forward only) == ELBO(training path)."""
+    import io, contextlib, os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    N, D, M, S = 100_000, 8, 256, 10
+    X, Y, Z = synthetic(N, D, M)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = DGP(X, Y, Z, [RBF(1.0, [1.0] * D) for _ in range(3)], [8, 8], Gaussian(), num_samples=S)
+    for l in m.layers[:-1]:
+        l.q_sqrt.assign(l.q_sqrt * 1e-1)
+    ctx = m._sync_model()
+    m._sync_data(m.data)
+    seed = 1234
+    ctx.grad_partial(S, seed, None)
+    e_train = ctx.grad_finish(want_elbo=True)
+    g = ctx.grad_get()
+    Ld, KL = ctx.elbo(S, seed, None)
+    assert abs((Ld - KL) - e_train) < 1e-11 * abs(e_train)
+    ctx.set_workspace_limit(12 << 30)                      # forces several chunks
+    Ld2, KL2 = ctx.elbo(S, seed, None)
+    assert abs((Ld2 - KL2) - e_train) < 1e-11 * abs(e_train)
+    ctx.grad_partial(S, seed, None)
+    assert abs(ctx.grad_finish(want_elbo=True) - e_train) < 1e-11 * abs(e_train)
+    np.testing.assert_allclose(ctx.grad_get(), g, rtol=1e-8, atol=1e-7 * np.abs(g).max())
+    ctx.set_workspace_limit(96 << 30)
+    # directional derivative: perturb Z, kernel parameters, q_mu, lower-triangular q_sqrt, likelihood variance
+    theta = ctx.params_get()
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal(theta.size)
+    segs = split_flat(m, np.arange(theta.size, dtype=np.float64))
+    for (i, k), idx in segs.items():
+        if k == "q_sqrt":                                     # only the lower triangle is a variable
+            idx = idx.astype(np.int64)
+            mask = np.triu(np.ones(idx.shape[-2:], dtype=bool), 1)
+            v[idx[..., mask].ravel()] = 0.0
+    v /= np.linalg.norm(v)
+    h = 1e-5
+    es = []
+    for sgn in (+1, -1):
+        ctx.params_set(theta + sgn * h * v)
+        a, b = ctx.elbo(S, seed, None)
+        es.append(a - b)
+    ctx.params_set(theta)
+    fd = (es[0] - es[1]) / (2 * h)
+    an = float(g @ v)
+    assert abs(fd - an) < 2e-5 * max(1.0, abs(an)), (fd, an)
