@@ -78,7 +78,14 @@ struct dgp_ctx {
   size_t ws_cap = 0;
   long ws_limit = 96L << 30;
   double *Cbar = nullptr, *Kbar = nullptr, *xbar = nullptr, *Gt = nullptr, *X1 = nullptr, *R1 = nullptr;
-  double* sm[10] = {nullptr};
+  // small-matrix scratch, one set per side stream: the per-layer chains (prep, gradient finish, natural-gradient
+  // step) are independent of each other and run concurrently, one layer per side stream (LayerFork below)
+  static constexpr int kSide = 3;
+  double* smset[kSide][10] = {{nullptr}};
+  double** sm = smset[0];
+  hipStream_t side[kSide] = {nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr};
+  bool use_side = true;
   std::vector<double*> zs_dev;
   std::vector<size_t> zs_cap;
   double* Xnew = nullptr;
@@ -194,6 +201,36 @@ GemmArgs mk(long M, long N, long K, const double* A, long lda, const double* B, 
   return a;
 }
 
+// Runs independent per-layer chains of small kernels concurrently: layer i goes to side stream i % kSide with its
+// own scratch set; the destructor joins everything back into the context's stream (also on error returns).
+struct LayerFork {
+  dgp_ctx* ctx;
+  hipStream_t main;
+  bool on;
+  ProfScope ps;
+  LayerFork(dgp_ctx* c, int n_items) : ctx(c), main(c->st), on(c->use_side && n_items > 1), ps(c, 2, 0, 0) {
+    if (!on) return;
+    (void)hipEventRecord(c->ev_fork, main);
+    for (int i = 0; i < dgp_ctx::kSide && i < n_items; ++i) (void)hipStreamWaitEvent(c->side[i], c->ev_fork, 0);
+    used = n_items < dgp_ctx::kSide ? n_items : dgp_ctx::kSide;
+  }
+  void use(int i) {
+    if (!on) return;
+    ctx->st = ctx->side[i % dgp_ctx::kSide];
+    ctx->sm = ctx->smset[i % dgp_ctx::kSide];
+  }
+  ~LayerFork() {
+    if (!on) return;
+    ctx->st = main;
+    ctx->sm = ctx->smset[0];
+    for (int i = 0; i < used; ++i) {
+      (void)hipEventRecord(ctx->ev_join[i], ctx->side[i]);
+      (void)hipStreamWaitEvent(main, ctx->ev_join[i], 0);
+    }
+  }
+  int used = 0;
+};
+
 // Split-K factor for the reductions over points: all active workgroups of such a launch run equally long, so
 // their number should fill whole rounds of the resident slots (2 workgroups per CU); `active_tiles` counts the
 // output tiles that survive the triangular skip, times the batch.
@@ -267,7 +304,7 @@ void free_model(dgp_ctx* ctx) {
   dev_free(ctx->params); dev_free(ctx->grad); dev_free(ctx->adam_m); dev_free(ctx->adam_v);
   dev_free(ctx->segs_dev); dev_free(ctx->mean_params); dev_free(ctx->acc_own);
   ctx->acc = nullptr;
-  for (auto& s : ctx->sm) dev_free(s);
+  for (auto& set : ctx->smset) for (auto& s : set) dev_free(s);
   for (auto& z : ctx->zs_dev) dev_free(z);
   ctx->zs_dev.clear(); ctx->zs_cap.clear();
   for (int k = 0; k < 3; ++k) {
@@ -355,10 +392,12 @@ inline const double* P(dgp_ctx* ctx, long off) { return ctx->params + off; }
 // ------------------------------------------------------------------------------- prep: small matrices + KL
 int prep(dgp_ctx* ctx, bool train = false) {
   HIPCHK(hipMemsetAsync(ctx->scal, 0, 4 * sizeof(double), ctx->st));
-  for (auto& y : ctx->L) {
+  LayerFork fork(ctx, (int)ctx->L.size());
+  for (size_t li = 0; li < ctx->L.size(); ++li) {
+    Layer& y = ctx->L[li];
+    fork.use((int)li);
     const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
     const long MM = (long)Mp * Mp;
-    ProfScope ps(ctx, 2, 0, 0);
     HIPCHK(pack_q(ctx->st, P(ctx, y.off_qsqrt), P(ctx, y.off_qmu), M, Mp, D, y.Lq, y.qmu_p));
     HIPCHK(rbf_kuu(ctx->st, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din, y.Kuu));
     HIPCHK(copy_mat(ctx->st, y.Kuu, y.Lu, MM));
@@ -538,6 +577,15 @@ int dgp_create(int device, void* hip_stream, dgp_ctx** out) {
   }
   (void)hipMemset(ctx->info, 0, sizeof(int));
   (void)hipMemset(ctx->scal, 0, 4 * sizeof(double));
+  {
+    const char* e = getenv("DGP_SIDE_STREAMS");
+    ctx->use_side = !(e && e[0] == '0');
+    bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < dgp_ctx::kSide && ok; ++i)
+      ok = hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) ctx->use_side = false;
+  }
   *out = ctx;
   return DGP_OK;
 }
@@ -550,6 +598,11 @@ void dgp_destroy(dgp_ctx* ctx) {
   dev_free(ctx->X); dev_free(ctx->Y); dev_free(ctx->scal); dev_free(ctx->info); dev_free(ctx->Xnew);
   if (ctx->ws) (void)hipFree(ctx->ws);
   for (auto e : ctx->prof.ev) (void)hipEventDestroy(e);
+  for (int i = 0; i < dgp_ctx::kSide; ++i) {
+    if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); }
+    if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+  }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->st);
   delete ctx;
 }
@@ -652,7 +705,7 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
   ctx->segs.push_back({off - 1, 1, TR_SOFTPLUS_SHIFT, 1, 0});
   RET(dev_alloc(ctx, &ctx->segs_dev, ctx->segs.size()));
   const size_t each = (size_t)Mpmax * Mpmax * Dmax;
-  for (auto& s : ctx->sm) RET(dev_alloc(ctx, &s, each));
+  for (auto& set : ctx->smset) for (auto& s : set) RET(dev_alloc(ctx, &s, each));
   return DGP_OK;
 }
 
@@ -813,12 +866,15 @@ int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out) {
   HIPCHK(hipSetDevice(ctx->device));
   double* acc = ctx->acc;
   double* g = ctx->grad;
-  for (auto& y : ctx->L) {
+  {
+  LayerFork fork(ctx, (int)ctx->L.size());
+  for (size_t li = 0; li < ctx->L.size(); ++li) {
+    Layer& y = ctx->L[li];
+    fork.use((int)li);
     const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
     const long MM = (long)Mp * Mp, DM = (long)D * Mp;
     double *T1 = ctx->sm[0], *T2 = ctx->sm[1], *T3 = ctx->sm[2], *T4 = ctx->sm[3], *Sm = ctx->sm[4];
     double *Gd = acc + y.acc_G, *du = acc + y.acc_du, *Q = acc + y.acc_Q, *dW = ctx->sm[5];
-    ProfScope ps(ctx, 2, 0, 0);
     {  // dW_d = 2 G_d W_d  (G_d symmetric, accumulated as its lower triangle)
       HIPCHK(symmetrize_lower(ctx->st, Gd, Mp, D));
       GemmArgs a = mk(Mp, Mp, Mp, Gd, Mp, y.Wcat, DM, dW, DM, 2.0, 0);
@@ -852,6 +908,7 @@ int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out) {
     HIPCHK(rbf_kuu_bwd(ctx->st, Sm, y.Kuu, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
                        g + y.off_Z, g + y.off_ls, g + y.off_var));
     HIPCHK(unpack_q_grads(ctx->st, y.dLq, y.dqmu_p, M, Mp, D, g + y.off_qsqrt, g + y.off_qmu));
+  }
   }
   HIPCHK(copy_mat(ctx->st, acc + 1, g + ctx->n_params - 1, 1));
   HIPCHK(sub_scalars(ctx->st, acc + 0, ctx->scal + 0, ctx->scal + 1));   // ELBO = data term - sum KL
@@ -906,14 +963,15 @@ int dgp_adam_step(dgp_ctx* ctx, double lr, double beta_1, double beta_2, double 
 
 int dgp_natgrad_step(dgp_ctx* ctx, double gamma, const uint8_t* layer_mask) {
   if (!ctx || !ctx->grad_ready) return fail(ctx, DGP_ERR_INVALID, "dgp_natgrad_step: no gradient (call dgp_grad_finish)");
+  LayerFork fork(ctx, (int)ctx->L.size());
   for (size_t l = 0; l < ctx->L.size(); ++l) {
     if (layer_mask && !layer_mask[l]) continue;
     Layer& y = ctx->L[l];
+    fork.use((int)l);
     const int M = y.d.M, Mp = y.Mp, D = y.d.D_out;
     const long MM = (long)Mp * Mp;
     double *Li = ctx->sm[0], *T = ctx->sm[1], *T1 = ctx->sm[2], *Gm = ctx->sm[3], *Pinv = ctx->sm[4], *Pn = ctx->sm[5],
            *Ri = ctx->sm[6], *Sn = ctx->sm[7];
-    ProfScope ps(ctx, 2, 0, 0);
     HIPCHK(trinv_lower(ctx->st, y.Lq, Li, ctx->sm[9], Mp, D));
     RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Lq, Mp, y.dLq, Mp, T, Mp, 1.0, 0, D, MM, MM, MM));
     HIPCHK(phi_tril_halfdiag(ctx->st, T, Mp, D));
