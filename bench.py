@@ -147,7 +147,7 @@ def main():
         achieved = mf["alg_flops"] / (mf["ms"] * 1e-3) / 1e12 if mf["ms"] > 0 else 0.0
         name, cus, mem = ctx.device_info()
         traffic = None          # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
-        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        tpath = os.environ.get("DGP_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
         if world == 1 and os.path.exists(tpath) and (args.N, args.M, args.S) == (100_000, 256, 10):
             try:
                 traffic = json.load(open(tpath))["hbm_bytes_per_launch"]

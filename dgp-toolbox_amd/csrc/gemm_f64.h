@@ -11,11 +11,17 @@
 //   C[M x N] (+)= alpha * op(A)[M x K] * op(B)[K x N]
 //   TA = false: A stored [M][K] (k contiguous);  TA = true: A stored [K][M] (m contiguous)
 //   TB = false: B stored [K][N] (n contiguous);  TB = true: B stored [N][K] (k contiguous)
-// LDS images keep the global orientation of each tile (so global loads and LDS stores are both
-// contiguous) and are padded so that the MFMA fragment reads (ds_read_b64, one f64 per lane) are
-// bank-conflict free: a k-contiguous image uses a row pitch of BK+2 doubles, an m/n-contiguous
-// image a pitch of BM+16 / BN+16 doubles (MI355X_MICROARCH.md §LDS: ds_read_b64 is serviced in two
-// 32-lane groups over 64 four-byte banks).
+// LDS images keep the global orientation of each tile (so global loads and LDS stores are contiguous).  Fragment
+// reads are 16-byte (ds_read_b128) wherever the layout allows: tools/lds_bench.hip measures ~210 B/clk/CU for
+// conflict-free b128 reads against ~120 for b64 on gfx950, and the engine was LDS-bound before (96 % LDS busy,
+// 21 % of it bank conflicts: rocprofv3 SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT).  Measured conflict-free pitches:
+//   k-contiguous image (A not transposed, B transposed): BK+4 doubles, a lane reads its two k values as one b128
+//     (pitch BK+2 is 2-way conflicted for both b64 and b128);
+//   n-contiguous B image: BN+8 doubles with the columns of every 16-column block stored grouped by (c mod 4),
+//     so that the four columns a lane feeds to the four MFMAs of a block are 32 contiguous bytes;
+//   m-contiguous A image (A transposed): BM+8 doubles, b64 reads of consecutive rows.
+//   (In both, the lane groups lk and lk+1 of a 32-lane half read image rows two apart: a pitch of 8 mod 16
+//   doubles puts them on opposite halves of the 64 banks; BN+16 / BM+16 were 2-way conflicted.)
 //
 // Matrix instruction: v_mfma_f64_4x4x4_4b_f64 issues at 16-18 cycles (72-74 TFLOP/s chip-wide, 94 % of
 // the 78.6 TFLOP/s fp64 spec) while v_mfma_f64_16x16x4_f64 sustains only ~100 cycles per instruction
@@ -25,6 +31,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace dgp {
 
@@ -80,8 +87,8 @@ template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int 
 struct GemmCfg {
   static constexpr int WM = BM / WR, WN = BN / WC;
   static constexpr int FM = WM / 16, FN = WN / 16;
-  static constexpr int LDA_S = TA ? (BM + 16) : (BK + 2);
-  static constexpr int LDB_S = TB ? (BK + 2) : (BN + 16);
+  static constexpr int LDA_S = TA ? (BM + 8) : (BK + 4);
+  static constexpr int LDB_S = TB ? (BK + 4) : (BN + 8);
   static constexpr int A_ROWS = TA ? BK : BM, A_COLS = TA ? BM : BK;
   static constexpr int B_ROWS = TB ? BN : BK, B_COLS = TB ? BK : BN;
   static constexpr int AS_SZ = A_ROWS * LDA_S, BS_SZ = B_ROWS * LDB_S;
@@ -89,7 +96,7 @@ struct GemmCfg {
   static constexpr int A_RPP = 256 / A_TPR, B_RPP = 256 / B_TPR;          // rows per pass
   static constexpr int A_PASS = (A_ROWS + A_RPP - 1) / A_RPP, B_PASS = (B_ROWS + B_RPP - 1) / B_RPP;
   static_assert(WR * WC == 4, "4 waves per workgroup");
-  static_assert(WM % 16 == 0 && WN % 16 == 0 && BK % 4 == 0, "MFMA tile granularity");
+  static_assert(WM % 16 == 0 && WN % 16 == 0 && BK % 16 == 0, "MFMA tile granularity (two 8-deep k steps per k-tile)");
   static_assert(256 % A_TPR == 0 && 256 % B_TPR == 0, "loader shape");
 };
 
@@ -117,14 +124,20 @@ __device__ __forceinline__ void tile_load(double (&reg)[PASS][V], const double* 
   }
 }
 
-template <int ROWS, int COLS, int V, int TPR, int RPP, int PASS, int LDS_LD>
+// position of column c inside the n-contiguous B image: columns of a 16-column block are grouped by (c mod 4)
+__device__ __forceinline__ int bpos(int c) { return (c & ~15) | ((c & 3) << 2) | ((c >> 2) & 3); }
+
+template <int ROWS, int COLS, int V, int TPR, int RPP, int PASS, int LDS_LD, bool PERM = false>
 __device__ __forceinline__ void tile_store(const double (&reg)[PASS][V], double* __restrict__ s, int tid) {
   const int tr = tid / TPR, tc = (tid % TPR) * V;
 #pragma unroll
   for (int p = 0; p < PASS; ++p) {
     const int r = p * RPP + tr;
     if (r < ROWS) {
-      if constexpr (V == 2) {
+      if constexpr (PERM) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) s[r * LDS_LD + bpos(tc + v)] = reg[p][v];
+      } else if constexpr (V == 2) {
         d2_t v = {reg[p][0], reg[p][1]};
         *reinterpret_cast<d2_t*>(s + r * LDS_LD + tc) = v;
       } else {
@@ -140,6 +153,10 @@ __device__ __forceinline__ void tile_store(const double (&reg)[PASS][V], double*
 // instructions per k-tile made the loop issue-bound (two waves share a SIMD's issue port with the MFMAs).
 // SCALED (FAST only): A-operand row scaling of GemmArgs::ascale_mode.
 template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int VB, bool FAST = false, bool SCALED = false>
+#ifndef DGP_WAVES_PER_EU   // two workgroups per CU (LDS allows no more): cap the register budget at 256 per lane
+#define DGP_WAVES_PER_EU 2
+#endif
+__attribute__((amdgpu_waves_per_eu(DGP_WAVES_PER_EU, DGP_WAVES_PER_EU)))
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   using Cfg = GemmCfg<TA, TB, BM, BN, BK, WR, WC, VA, VB>;
   constexpr int FM = Cfg::FM, FN = Cfg::FN;
@@ -264,68 +281,147 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     double* as = smem + buf * (Cfg::AS_SZ + Cfg::BS_SZ);
     double* bs = as + Cfg::AS_SZ;
     tile_store<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS, Cfg::LDA_S>(ra, as, tid);
-    tile_store<Cfg::B_ROWS, Cfg::B_COLS, VB, Cfg::B_TPR, Cfg::B_RPP, Cfg::B_PASS, Cfg::LDB_S>(rb, bs, tid);
+    tile_store<Cfg::B_ROWS, Cfg::B_COLS, VB, Cfg::B_TPR, Cfg::B_RPP, Cfg::B_PASS, Cfg::LDB_S, !TB>(rb, bs, tid);
   };
 
-  auto compute = [&](int cur) {
-    const double* as = smem + cur * (Cfg::AS_SZ + Cfg::BS_SZ);
-    const double* bs = as + Cfg::AS_SZ;
+  // One k-step feeds 8 k values to 2 x 32 MFMAs: lane (li, lk) supplies k = 8 s + 2 lk + q in half-step q (any
+  // assignment of k to the instruction's four k slots is legal as long as A and B agree), so that its two values
+  // are adjacent in a k-contiguous image.  v_mfma_f64_4x4x4_4b multiplies, for each of its four blocks b, rows
+  // 4b..4b+3 of the A fragment with the columns supplied by lanes 4b..4b+3: lane c supplies column 4e + (c & 3) of
+  // the 16-column block for the e-th MFMA, so MFMA e yields the 16 x 4 strip of columns 4e..4e+3.
+  //
+  // Pipeline: the unit of work is a half-step (32 MFMAs).  The LDS reads of unit u+1 are issued under the MFMAs
+  // of unit u (B fragments per half-step, A fragments per step because one b128 read brings both halves), also
+  // ACROSS the k-tile barrier: the barrier sits before the LAST half-step, whose MFMAs cover the first reads of
+  // the next k-tile.  The next tile's LDS stores are issued under the half-step that ends step NS-2, long before
+  // the barrier that publishes them.  sched_group_barrier pins the interleaving (one LDS instruction, then a few
+  // MFMAs): issued back to back, the LDS instructions fill the LDS queue and the wave, which issues in order, sits
+  // in front of its own MFMAs.  Measured on the dense K = D*Mp product (tools/gemm_bench): 75.7 TFLOP/s with all
+  // LDS/global traffic removed, 55 with everything issued at the point of use, 63 with this schedule.
+  constexpr int NS = BK / 8;
+  static_assert(NS % 2 == 0, "fragment ping-pong needs an even number of k-steps per k-tile");
+  double fa[2][2][FM], fb[2][FN][4];
+  auto fragA = [&](int buf, int s8, double (&xa)[2][FM]) {
+    const double* as = smem + buf * (Cfg::AS_SZ + Cfg::BS_SZ);
+    const int kk = s8 * 8 + lk * 2;
 #pragma unroll
-    for (int k4 = 0; k4 < BK / 4; ++k4) {
-#ifdef DGP_ABLATE_LDSREAD
-      const int kk = lk;
+    for (int i = 0; i < FM; ++i) {
+      const int row = (i * WR + wr) * 16 + li;
+#ifdef DGP_ABLATE_NOLDS
+      xa[0][i] = (double)(row + kk) * g.alpha; xa[1][i] = (double)(row - kk) * g.alpha;
 #else
-      const int kk = k4 * 4 + lk;
-#endif
-      double fa[FM], fb[FN][4];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int row = (i * WR + wr) * 16 + li;
-        fa[i] = TA ? as[kk * Cfg::LDA_S + row] : as[row * Cfg::LDA_S + kk];
+      if constexpr (TA) {
+        xa[0][i] = as[kk * Cfg::LDA_S + row];
+        xa[1][i] = as[(kk + 1) * Cfg::LDA_S + row];
+      } else {
+        const d2_t v = *reinterpret_cast<const d2_t*>(as + row * Cfg::LDA_S + kk);
+        xa[0][i] = v[0]; xa[1][i] = v[1];
       }
-      // v_mfma_f64_4x4x4_4b computes the four diagonal 4x4 blocks of (A frag) x (B frag); rotating the
-      // B fragment's columns by 4r inside its 16-column block yields the r-th block diagonal.
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = (j * WC + wc) * 16 + ((li + 4 * r) & 15);
-          fb[j][r] = TB ? bs[col * Cfg::LDB_S + kk] : bs[kk * Cfg::LDB_S + col];
-        }
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#ifdef DGP_ABLATE_MFMA
-            acc[i][j][r] += fa[i] + fb[j][r];
-#else
-            acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[i], fb[j][r], acc[i][j][r], 0, 0, 0);
 #endif
     }
   };
+  auto fragB = [&](int buf, int s8, int q, double (&xb)[FN][4]) {
+    const double* bs = smem + buf * (Cfg::AS_SZ + Cfg::BS_SZ) + Cfg::AS_SZ;
+    const int kk = s8 * 8 + lk * 2 + q;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int cb = (j * WC + wc) * 16;
+#ifdef DGP_ABLATE_NOLDS
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xb[j][e] = (double)(cb + e - kk) * g.alpha;
+#else
+      if constexpr (TB) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xb[j][e] = bs[(cb + 4 * e + (li & 3)) * Cfg::LDB_S + kk];
+      } else {
+        const double* pq = bs + kk * Cfg::LDB_S + cb + (li & 3) * 4;
+        const d2_t v0 = *reinterpret_cast<const d2_t*>(pq), v1 = *reinterpret_cast<const d2_t*>(pq + 2);
+        xb[j][0] = v0[0]; xb[j][1] = v0[1]; xb[j][2] = v1[0]; xb[j][3] = v1[1];
+      }
+#endif
+    }
+  };
+  auto mma = [&](const double (&xa)[FM], const double (&xb)[FN][4]) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[i][j][e] = __builtin_amdgcn_mfma_f64_4x4x4f64(xa[i], xb[j][e], acc[i][j][e], 0, 0, 0);
+  };
+  constexpr int N_MFMA = FM * FN * 4;                               // per half-step
+  constexpr int N_RA = TA ? 2 * FM : FM, N_RB = TB ? 4 * FN : 2 * FN;   // LDS read instructions of fragA / fragB
+  constexpr int N_WRITE = Cfg::A_PASS + (TB ? 1 : 2) * Cfg::B_PASS;
+  auto hint = [&](auto nw_c, auto nr_c) {   // nw LDS writes first, then nr LDS reads, spread over the unit's MFMAs
+    constexpr int nw = decltype(nw_c)::value, nr = decltype(nr_c)::value;
+    constexpr int per = N_MFMA / (nw + nr) > 0 ? N_MFMA / (nw + nr) : 1;
+#pragma unroll
+    for (int n = 0; n < nw; ++n) {
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // one DS write
+      __builtin_amdgcn_sched_group_barrier(0x008, per, 0);   // `per` MFMAs
+    }
+#pragma unroll
+    for (int n = 0; n < nr; ++n) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+    }
+    if constexpr (N_MFMA - per * (nw + nr) > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA - per * (nw + nr), 0);
+  };
+  using std::integral_constant;
+  // One k-tile.  `stage_next` stores the prefetched next tile into the other LDS buffer: unconditionally (after
+  // the last k-tile it rewrites stale registers into a buffer nobody reads before the next prologue), so that the
+  // stores sit in the same basic block as the MFMAs.  That buffer was last read before the previous barrier
+  // (every wave drains its LDS reads before it arrives there).  `fetch_next2` starts the global loads of a later
+  // tile into the registers the store has freed.
+  auto ktile = [&](int cur, auto&& stage_next, auto&& fetch_next2) {
+#pragma unroll
+    for (int s8 = 0; s8 < NS; ++s8) {
+      // half-step (s8, 0): B fragments of (s8, 1) fly
+      fragB(cur, s8, 1, fb[1]);
+      mma(fa[s8 & 1][0], fb[0]);
+      hint(integral_constant<int, 0>{}, integral_constant<int, N_RB>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (s8 < NS - 1) {
+        // half-step (s8, 1): fragments of (s8 + 1, 0) fly; the last such unit also carries the LDS stores
+        if (s8 == NS - 2) stage_next();
+        fragA(cur, s8 + 1, fa[(s8 + 1) & 1]);
+        fragB(cur, s8 + 1, 0, fb[0]);
+        mma(fa[s8 & 1][1], fb[1]);
+        if (s8 == NS - 2) hint(integral_constant<int, N_WRITE>{}, integral_constant<int, N_RA + N_RB>{});
+        else hint(integral_constant<int, 0>{}, integral_constant<int, N_RA + N_RB>{});
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+#ifndef DGP_ABLATE_BARRIER
+        __syncthreads();
+#endif
+        fetch_next2();                       // issues the next global loads if a tile is left (uniform branch)
+        __builtin_amdgcn_sched_barrier(0);
+        // last half-step: the first fragments of the next k-tile fly (harmless after the last k-tile: valid LDS)
+        fragA(cur ^ 1, 0, fa[0]);
+        fragB(cur ^ 1, 0, 0, fb[0]);
+        mma(fa[s8 & 1][1], fb[1]);
+        hint(integral_constant<int, 0>{}, integral_constant<int, N_RA + N_RB>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  auto first_frags = [&]() { fragA(0, 0, fa[0]); fragB(0, 0, 0, fb[0]); };
 
   if constexpr (!FAST) {
+    // Generic path (edge tiles, unaligned operands): predicated loads.  The triangular structure is
+    // exploited at tile level only (k-range per tile, tiles above the diagonal skipped): in-loop predication
+    // of the MFMAs made hipcc move the accumulators between VGPRs and AGPRs around every MFMA (2.3x slower).
     if (ktiles > 0) {
       gload();
       sstore(0);
     }
     __syncthreads();
-    // Generic main loop (edge tiles, unaligned operands): predicated loads.  The triangular structure is
-    // exploited at tile level only (k-range per tile, tiles above the diagonal skipped): in-loop predication
-    // of the MFMAs made hipcc move the accumulators between VGPRs and AGPRs around every MFMA (2.3x slower).
+    if (ktiles > 1) gload();
+    if (ktiles > 0) first_frags();
     for (long kt = 0; kt < ktiles; ++kt) {
       const int cur = (int)(kt & 1);
-      const bool more = (kt + 1 < ktiles);
-#ifndef DGP_ABLATE_GLOBAL
-      if (more) gload();                             // next tile's global loads fly under the MFMAs
-#endif
-      compute(cur);
-#ifndef DGP_ABLATE_GLOBAL
-      if (more) sstore(cur ^ 1);
-#endif
-      __syncthreads();
+      ktile(cur, [&]() { sstore(cur ^ 1); }, [&]() { if (kt + 2 < ktiles) gload(); });
     }
   } else {
     // ---- interior fast path: running pointers, unconditional 16-byte loads, no predicates ----
@@ -333,34 +429,44 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     const int a_tr = tid / Cfg::A_TPR, a_tc = (tid % Cfg::A_TPR) * 2;
     const int b_tr = tid / Cfg::B_TPR, b_tc = (tid % Cfg::B_TPR) * 2;
     const bool wrap = (!TA) && SCALED;                         // ascale_mode 1: K wraps around a_kblk physical columns
-    const double* pa = TA ? A + (klo + a_tr) * g.lda + m0 + a_tc : A + (m0 + a_tr) * g.lda + (wrap ? 0 : klo) + a_tc;
-    const double* pb = TB ? B + (n0 + b_tr) * g.ldb + klo + b_tc : B + (klo + b_tr) * g.ldb + n0 + b_tc;
-    const long a_pass = (long)Cfg::A_RPP * g.lda, b_pass = (long)Cfg::B_RPP * g.ldb;
-    const long a_kstride = TA ? g.lda : 1, b_kstride = TB ? 1 : g.ldb;
+    // Addressing: one wave-uniform base pointer per operand (scalar registers, advanced per k-tile) plus constant
+    // 32-bit per-lane byte offsets, so that the loads use the scalar-base form and no 64-bit vector adds.
+    const char* ua = reinterpret_cast<const char*>(TA ? A + klo * g.lda + m0 : A + m0 * g.lda + (wrap ? 0 : klo));
+    const char* ub = reinterpret_cast<const char*>(TB ? B + n0 * g.ldb + klo : B + klo * g.ldb + n0);
+    unsigned offa[Cfg::A_PASS], offb[Cfg::B_PASS], offs[Cfg::A_PASS];
+#pragma unroll
+    for (int p = 0; p < Cfg::A_PASS; ++p) offa[p] = (unsigned)(((long)(p * Cfg::A_RPP + a_tr) * g.lda + a_tc) * 8);
+#pragma unroll
+    for (int p = 0; p < Cfg::B_PASS; ++p) offb[p] = (unsigned)(((long)(p * Cfg::B_RPP + b_tr) * g.ldb + b_tc) * 8);
+    const long a_kstride = (TA ? g.lda : 1) * 8, b_kstride = (TB ? 1 : g.ldb) * 8;   // bytes per unit of k
     // scale source: mode 1 -> ascale[(m0 + row)*as_ld + d], constant within a d-block; mode 2 -> ascale[k*as_ld + batch]
-    const double* ps = nullptr;
-    long s_pass = 0, s_kstride = 0;
+    const char* us = nullptr;
+    long s_kstride = 0;
     if constexpr (SCALED) {
       // transposed A: a tile row is one k (point) and is loaded by a single wave (A_TPR == 64), so its scale is
       // wave-uniform: address it through the scalar wave index and hipcc emits scalar (s_load) fetches
       const int a_tr_s = (TA && Cfg::A_TPR == 64) ? wave : a_tr;
-      ps = TA ? g.ascale + (klo + a_tr_s) * g.as_ld + bz : g.ascale + (m0 + a_tr) * g.as_ld;
-      s_pass = (long)Cfg::A_RPP * g.as_ld;
-      s_kstride = TA ? g.as_ld : 0;
+      us = reinterpret_cast<const char*>(TA ? g.ascale + klo * g.as_ld + bz : g.ascale + m0 * g.as_ld);
+#pragma unroll
+      for (int p = 0; p < Cfg::A_PASS; ++p) offs[p] = (unsigned)(((long)(p * Cfg::A_RPP + a_tr_s) * g.as_ld) * 8);
+      s_kstride = TA ? g.as_ld * 8 : 0;
     }
     const long jump = kblen - (ktiles_per_blk - 1) * BK;      // k advance when crossing a triangular block boundary
     const long tiles_per_wrap = wrap ? g.a_kblk / BK : 0;
     long kk_in_blk = 0, kk_in_wrap = 0;
-    d2_t fra[Cfg::A_PASS], frb[Cfg::B_PASS];
-    double fsc[Cfg::A_PASS];
-    auto fload = [&]() {
+    // Two register sets: the global loads of k-tile u go to set u & 1 and are issued TWO k-tiles before the tile is
+    // stored to LDS (with one tile of lead the stores waited on HBM latency: removing the global->LDS staging
+    // from the loop was worth 61 -> 72 TFLOP/s on the dense K = D*Mp product).
+    d2_t fra[2][Cfg::A_PASS], frb[2][Cfg::B_PASS];
+    double fsc[2][Cfg::A_PASS];
+    auto fload = [&](int set) {
 #pragma unroll
-      for (int p = 0; p < Cfg::A_PASS; ++p) fra[p] = *reinterpret_cast<const d2_t*>(pa + p * a_pass);
+      for (int p = 0; p < Cfg::A_PASS; ++p) fra[set][p] = *reinterpret_cast<const d2_t*>(ua + offa[p]);
 #pragma unroll
-      for (int p = 0; p < Cfg::B_PASS; ++p) frb[p] = *reinterpret_cast<const d2_t*>(pb + p * b_pass);
+      for (int p = 0; p < Cfg::B_PASS; ++p) frb[set][p] = *reinterpret_cast<const d2_t*>(ub + offb[p]);
       if constexpr (SCALED) {
 #pragma unroll
-        for (int p = 0; p < Cfg::A_PASS; ++p) fsc[p] = ps[p * s_pass];
+        for (int p = 0; p < Cfg::A_PASS; ++p) fsc[set][p] = *reinterpret_cast<const double*>(us + offs[p]);
       }
       // advance the cursors (uniform, scalar)
       long ka = BK, kbs = BK;
@@ -368,41 +474,54 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       if (kk_in_blk == ktiles_per_blk) { kk_in_blk = 0; ka = jump; kbs = jump; }
       if (wrap) {
         kk_in_wrap += 1;
-        if (kk_in_wrap == tiles_per_wrap) { kk_in_wrap = 0; ka = BK - g.a_kblk; if constexpr (SCALED) ps += 1; }
+        if (kk_in_wrap == tiles_per_wrap) { kk_in_wrap = 0; ka = BK - g.a_kblk; if constexpr (SCALED) us += 8; }
       }
-      pa += ka * a_kstride;
-      pb += kbs * b_kstride;
-      if constexpr (SCALED) ps += BK * s_kstride;
+      ua += ka * a_kstride;
+      ub += kbs * b_kstride;
+      if constexpr (SCALED) us += BK * s_kstride;
     };
-    auto fstore = [&](int buf) {
+    auto fstore = [&](int set, int buf) {
       double* as = smem + buf * (Cfg::AS_SZ + Cfg::BS_SZ);
       double* bs = as + Cfg::AS_SZ;
 #pragma unroll
       for (int p = 0; p < Cfg::A_PASS; ++p) {
-        d2_t v = fra[p];
-        if constexpr (SCALED) { v[0] *= fsc[p]; v[1] *= fsc[p]; }
+        d2_t v = fra[set][p];
+        if constexpr (SCALED) { v[0] *= fsc[set][p]; v[1] *= fsc[set][p]; }
         *reinterpret_cast<d2_t*>(as + (p * Cfg::A_RPP + a_tr) * Cfg::LDA_S + a_tc) = v;
       }
 #pragma unroll
-      for (int p = 0; p < Cfg::B_PASS; ++p)
-        *reinterpret_cast<d2_t*>(bs + (p * Cfg::B_RPP + b_tr) * Cfg::LDB_S + b_tc) = frb[p];
+      for (int p = 0; p < Cfg::B_PASS; ++p) {
+        if constexpr (TB) {
+          *reinterpret_cast<d2_t*>(bs + (p * Cfg::B_RPP + b_tr) * Cfg::LDB_S + b_tc) = frb[set][p];
+        } else {   // columns b_tc, b_tc + 1 (b_tc even) land 4 doubles apart in the grouped image
+          double* q = bs + (p * Cfg::B_RPP + b_tr) * Cfg::LDB_S + bpos(b_tc);
+          q[0] = frb[set][p][0];
+          q[4] = frb[set][p][1];
+        }
+      }
     };
     if (ktiles > 0) {
-      fload();
-      fstore(0);
+      fload(0);
+      fstore(0, 0);
     }
     __syncthreads();
-    for (long kt = 0; kt < ktiles; ++kt) {
-      const int cur = (int)(kt & 1);
-      const bool more = (kt + 1 < ktiles);
-      if (more) fload();
-      compute(cur);
-      if (more) fstore(cur ^ 1);
-      __syncthreads();
+    if (ktiles > 1) fload(1);
+    if (ktiles > 2) fload(0);
+    if (ktiles > 0) first_frags();
+    // k-tile kt reads LDS buffer kt & 1, stores tile kt+1 (register set (kt+1) & 1) and then refills that set
+    // with tile kt+3; two tiles per trip keep the set indices compile-time.
+    for (long kt = 0; kt < ktiles; kt += 2) {
+#ifndef DGP_ABLATE_GLOBAL
+      ktile(0, [&]() { fstore(1, 1); }, [&]() { if (kt + 3 < ktiles) fload(1); });
+      if (kt + 1 < ktiles) ktile(1, [&]() { fstore(0, 0); }, [&]() { if (kt + 4 < ktiles) fload(0); });
+#else
+      ktile(0, [&]() {}, [&]() {});
+      if (kt + 1 < ktiles) ktile(1, [&]() {}, [&]() {});
+#endif
     }
   }
 
-  // ---- epilogue: acc[i][j][r] of lane l is C[rowblk*16 + 4*((l&15)>>2) + (l>>4)][colblk*16 + ((l&15) + 4r) & 15]
+  // ---- epilogue: acc[i][j][e] of lane l is C[rowblk*16 + 4*((l&15)>>2) + (l>>4)][colblk*16 + 4e + (l&3)]
   if (g.epi != 0) {
     // per-row sums of squares over this wave's columns: a lane holds 4 values of its row per fragment, the
     // 4 lanes l&3 = 0..3 of a quad hold the rest of that row's 16 columns
@@ -429,7 +548,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       const long row = m0 + (long)(i * WR + wr) * 16 + 4 * (li >> 2) + lk;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long col = n0 + (long)(j * WC + wc) * 16 + ((li + 4 * r) & 15);
+        const long col = n0 + (long)(j * WC + wc) * 16 + 4 * r + (li & 3);
         if (row < g.M && col < g.N) {
           double* p = C + row * g.ldc + col;
           double v = g.alpha * acc[i][j][r];

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
+#include <string>
 #include "gemm_f64.h"
 using namespace dgp;
 
@@ -16,7 +17,7 @@ double run(const char* name, long M, long N, long K, int splits, int tri, long t
   a.sA = a.sB = a.sC = 0; a.batch = 1; a.splits = splits; a.alpha = 1.0; a.beta = splits > 1 ? 1 : 0; a.tri = tri; a.triblk = triblk;
   long per = (K + splits - 1) / splits; per = ((per + BK - 1) / BK) * BK; a.ksplit = per; a.splits = (int)((K + per - 1) / per);
   const long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  dim3 grid((unsigned)tiles, (unsigned)a.splits);
+  dim3 grid((unsigned)(a.splits == 1 && tiles > 4088 ? 4088 : tiles), (unsigned)a.splits);   // persistent, as the library launches
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, 2, 2, FAST, false>), grid, dim3(256), 0, 0, a);
   hipDeviceSynchronize();
@@ -86,6 +87,12 @@ int main(int argc, char** argv) {
 #define CB(BM, BN, BK, WR, WC) run<false, false, BM, BN, BK, WR, WC, true>("NN  Cbar=C'*Scat dense K=D*Mp", P, Mp, DM, 1, 0, 0, A, B, C, DM, Mp, Mp, 1.0)
 #define TT(BM, BN, BK, WR, WC) run<false, false, BM, BN, BK, WR, WC, true>("NN  Tt=Ct*Wcat tri K=Mp", P, DM, Mp, 1, TRI_B_LOWER, Mp, A, B, C, Mp, DM, DM, 0.5 + 0.5 * BN / Mp)
 #define GR(BM, BN, BK, WR, WC) run<true, false, BM, BN, BK, WR, WC, true>("TN  G=Ct^T*Ct (K=P) splits", Mp, DM, P, 48, TRI_OUT_LOWER, Mp, B + Mp * DM, A, C, Mp, DM, DM, 0.75)
+  if (argc > 2 && std::string(argv[2]) == "tiles") {   // k-depth / occupancy sweep of the interior kernel
+    CB(128, 64, 16, 2, 2);
+    TT(128, 64, 16, 2, 2);
+    GR(128, 64, 16, 2, 2);
+    return 0;
+  }
   {
     double* vb; hipMalloc(&vb, P * D * 8); hipMemset(vb, 0, P * D * 8);
     double* Ct = B + Mp * DM;   // [P x Mp]
