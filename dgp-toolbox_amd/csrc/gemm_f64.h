@@ -156,7 +156,9 @@ template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int 
 #ifndef DGP_WAVES_PER_EU   // two workgroups per CU (LDS allows no more): cap the register budget at 256 per lane
 #define DGP_WAVES_PER_EU 2
 #endif
+#if DGP_WAVES_PER_EU > 0
 __attribute__((amdgpu_waves_per_eu(DGP_WAVES_PER_EU, DGP_WAVES_PER_EU)))
+#endif
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   using Cfg = GemmCfg<TA, TB, BM, BN, BK, WR, WC, VA, VB>;
   constexpr int FM = Cfg::FM, FN = Cfg::FN;
@@ -171,6 +173,9 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   // (measured: early-exit workgroups were as expensive as running ones), which dominated the short-K products.
   // Every wave of the workgroup takes the same trip count, so the barriers inside stay uniform.
   const unsigned nlin = grouped ? gridDim.x : ntile;
+#ifdef DGP_CLOCK_STAMPS   // tuning only: shader-clock cycles and 100 MHz ticks spent by this workgroup
+  const long long stamp_c0 = clock64(), stamp_r0 = wall_clock64();
+#endif
   for (unsigned lin = blockIdx.x; lin < nlin; lin += gridDim.x) {
   unsigned bid, bz, sp;
   if (grouped) {
@@ -566,6 +571,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     }
   }
   }   // persistent tile loop
+#ifdef DGP_CLOCK_STAMPS
+  if (threadIdx.x == 0 && g.C2 == nullptr && g.emul != nullptr) {
+    long long* st = reinterpret_cast<long long*>(const_cast<double*>(g.emul));
+    st[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = clock64() - stamp_c0;
+    st[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64() - stamp_r0;
+  }
+#endif
 }
 
 // Host-side dispatcher (defined in gemm_f64.hip)

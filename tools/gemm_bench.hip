@@ -28,14 +28,15 @@ double run(const char* name, long M, long N, long K, int splits, int tri, long t
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
 #ifdef DGP_CLOCK_STAMPS
   {
-    long long* st; hipMalloc(&st, tiles * 16); hipMemset(st, 0, tiles * 16);
+    const long nwg = (long)grid.x * grid.y;
+    long long* st; hipMalloc(&st, nwg * 16); hipMemset(st, 0, nwg * 16);
     GemmArgs b = a; b.emul = reinterpret_cast<const double*>(st); b.C2 = nullptr;
     hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, 2, 2, FAST, false>), grid, dim3(256), 0, 0, b);
     hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, 2, 2, FAST, false>), grid, dim3(256), 0, 0, b);
     hipDeviceSynchronize();
-    std::vector<long long> h(2 * tiles); hipMemcpy(h.data(), st, tiles * 16, hipMemcpyDeviceToHost);
+    std::vector<long long> h(2 * nwg); hipMemcpy(h.data(), st, nwg * 16, hipMemcpyDeviceToHost);
     std::vector<double> ghz;
-    for (long t = 0; t < tiles; ++t) if (h[2 * t + 1] > 0) ghz.push_back((double)h[2 * t] / ((double)h[2 * t + 1] / 100e6) / 1e9);
+    for (long t = 0; t < nwg; ++t) if (h[2 * t + 1] > 0) ghz.push_back((double)h[2 * t] / ((double)h[2 * t + 1] / 100e6) / 1e9);
     std::sort(ghz.begin(), ghz.end());
     if (!ghz.empty()) printf("      in-kernel shader clock: median %.2f GHz (p10 %.2f, p90 %.2f) over %zu workgroups\n", ghz[ghz.size() / 2], ghz[ghz.size() / 10], ghz[ghz.size() * 9 / 10], ghz.size());
     hipFree(st);
