@@ -470,7 +470,18 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
 }
 
 // ------------------------------------------------------------------------------- backward over one chunk
-int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool use_zs) {
+// `params`: accumulate the parameter-gradient partial sums (training).  `xgrad0`: also produce the gradient with
+// respect to the first layer's inputs (ctx->xbar, [Nc x D_in0]) -- the vector-Jacobian product used on the
+// acquisition side (reference: tf.GradientTape on x, Infill_criteria.py:79-85).
+struct BwdOpts {
+  const double* X;   // inputs of the first layer (device), all Ntot rows
+  long Ntot;
+  long n_goff;
+  bool params;
+  bool xgrad0;
+};
+
+int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool use_zs, const BwdOpts& o) {
   const int nl = (int)ctx->L.size();
   double* acc = ctx->acc;
   for (int l = nl - 1; l >= 0; --l) {
@@ -478,7 +489,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
     const bool dedup = (l == 0);
     const long Pl = dedup ? Nc : (long)S * Nc;
-    const double* Xin = dedup ? ctx->X : ctx->L[l - 1].F;
+    const double* Xin = dedup ? o.X : ctx->L[l - 1].F;
     const long row0 = dedup ? n0 : 0;
     const long DM = (long)D * Mp, MM = (long)Mp * Mp;
     const double tri1 = (double)Pl * Mp * (Mp + 1.0);
@@ -496,6 +507,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       RET(GX(ctx, 0, GEMM_NN, a, tri1, (double)Pl * Mp * 32));
     }
     // reductions over the chunk's points (accumulate into the all-reduce buffer)
+    if (o.params) {
     {  // G_d = sum_p vbar_pd c_p c_p^T   (lower triangle; dW_d = 2 G_d W_d after the all-reduce)
       GemmArgs a = mk(Mp, Mp, Pl, y.Ct, Mp, y.Ct, Mp, acc + y.acc_G, Mp, 1.0, 1);
       a.batch = D; a.sC = MM; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp) * D, Pl, (long)Mp * 8);
@@ -512,6 +524,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       a.splits = pick_splits(ctx, Mp, D, Pl);
       RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
     }
+    }
     {  // RBF backward through Kuf: two skinny contractions of g with [Z | 1] and [X | 1]
       const int w1 = Din + 1;
       {
@@ -519,19 +532,21 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
         HIPCHK(make_x1(ctx->st, Xin, row0, Pl, Din, ctx->X1));
       }
       RET(GX(ctx, 0, GEMM_NN, mk(Pl, w1, Mp, ctx->Gt, Mp, y.Z1, w1, ctx->R1, w1), 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
-      GemmArgs a = mk(Mp, w1, Pl, ctx->Gt, Mp, ctx->X1, w1, acc + y.acc_GX, w1, 1.0, 1);
-      a.splits = pick_splits(ctx, Mp, w1, Pl);
-      RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
+      if (o.params) {
+        GemmArgs a = mk(Mp, w1, Pl, ctx->Gt, Mp, ctx->X1, w1, acc + y.acc_GX, w1, 1.0, 1);
+        a.splits = pick_splits(ctx, Mp, w1, Pl);
+        RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
+      }
       ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 24);
       HIPCHK(xbar_finish(ctx->st, ctx->R1, ctx->X1, Pl, P(ctx, y.off_ls), Din, D, y.d.mean_kind, y.meanW, y.mbar,
-                         l > 0 ? 1 : 0, ctx->xbar, acc + y.acc_x2));
+                         (l > 0 || o.xgrad0) ? 1 : 0, ctx->xbar, o.params ? acc + y.acc_x2 : nullptr));
     }
     if (l > 0) {
       Layer& w = ctx->L[l - 1];
       ProfScope ps(ctx, 1, 0, (double)S * Nc * Din * 24);
       HIPCHK(fold_sample_grad(ctx->st, ctx->xbar, w.var, Nc, S, (l - 1 == 0) ? 1 : 0, w.d.D_out,
-                              zsrc_of(ctx, l - 1, use_zs, seed, ctx->n_goff, ctx->N), n0, w.mbar, w.vbar,
-                              acc + w.acc_dvar));
+                              zsrc_of(ctx, l - 1, use_zs, seed, o.n_goff, o.Ntot), n0, w.mbar, w.vbar,
+                              o.params ? acc + w.acc_dvar : nullptr));
     }
   }
   return DGP_OK;
@@ -822,6 +837,48 @@ int dgp_propagate(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint6
   return check_flags(ctx);
 }
 
+int dgp_propagate_vjp(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
+                      const double* f_bar, const double* mean_bar, const double* var_bar, double* xbar_out) {
+  RET(check_ready(ctx, false));
+  if (!Xnew || !xbar_out || Nn <= 0 || S <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_propagate_vjp: bad arguments");
+  if (!f_bar && !mean_bar && !var_bar) return fail(ctx, DGP_ERR_INVALID, "dgp_propagate_vjp: no cotangent given");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nl = (int)ctx->L.size();
+  const int Din0 = ctx->L[0].d.D_in;
+  Layer& last = ctx->L.back();
+  const int DL = last.d.D_out;
+  RET(grow(ctx, &ctx->Xnew, &ctx->Xnew_cap, (size_t)Nn * Din0));
+  HIPCHK(hipMemcpyAsync(ctx->Xnew, Xnew, (size_t)Nn * Din0 * 8, hipMemcpyHostToDevice, ctx->st));
+  if (zs) RET(upload_zs(ctx, zs, S, Nn));
+  // the output staging buffers of dgp_propagate double as staging for the cotangents ([S, Nn, D_L] each)
+  const double* host_bar[3] = {f_bar, mean_bar, var_bar};
+  const double* dev_bar[3] = {nullptr, nullptr, nullptr};
+  for (int k = 0; k < 3; ++k) {
+    if ((int)ctx->out_dev[k].size() < nl) { ctx->out_dev[k].resize(nl, nullptr); ctx->out_cap[k].resize(nl, 0); }
+    if (!host_bar[k]) continue;
+    const size_t n = (size_t)S * Nn * DL;
+    RET(grow(ctx, &ctx->out_dev[k][nl - 1], &ctx->out_cap[k][nl - 1], n));
+    HIPCHK(hipMemcpyAsync(ctx->out_dev[k][nl - 1], host_bar[k], n * 8, hipMemcpyHostToDevice, ctx->st));
+    dev_bar[k] = ctx->out_dev[k][nl - 1];
+  }
+  RET(prep(ctx, true));
+  long Nc = 0;
+  RET(ensure_ws(ctx, Nn, S, true, &Nc));
+  const bool dedup_last = nl == 1;
+  for (long n0 = 0; n0 < Nn; n0 += Nc) {
+    const long nc = std::min(Nc, (long)Nn - n0);
+    RET(forward_chunk(ctx, ctx->Xnew, Nn, n0, nc, S, seed, zs != nullptr, 0));
+    {
+      ProfScope ps(ctx, 1, 0, 0);
+      HIPCHK(vjp_seed(ctx->st, dev_bar[0], dev_bar[1], dev_bar[2], last.var, nc, S, dedup_last ? 1 : 0, DL,
+                      zsrc_of(ctx, nl - 1, zs != nullptr, seed, 0, Nn), Nn, n0, last.mbar, last.vbar));
+    }
+    RET(backward_chunk(ctx, n0, nc, S, seed, zs != nullptr, BwdOpts{ctx->Xnew, (long)Nn, 0, false, true}));
+    HIPCHK(hipMemcpyAsync(xbar_out + n0 * Din0, ctx->xbar, (size_t)nc * Din0 * 8, hipMemcpyDeviceToHost, ctx->st));
+  }
+  return check_flags(ctx);
+}
+
 int dgp_grad_partial(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs) {
   RET(check_ready(ctx, true));
   if (S <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_grad_partial: S must be positive");
@@ -843,7 +900,7 @@ int dgp_grad_partial(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const
                        P(ctx, ctx->n_params - 1), ctx->acc + 0, ctx->acc + 1, last.mbar, last.vbar,
                        ctx->acc + last.acc_dvar));
     }
-    RET(backward_chunk(ctx, n0, nc, S, seed, zs != nullptr));
+    RET(backward_chunk(ctx, n0, nc, S, seed, zs != nullptr, BwdOpts{ctx->X, ctx->N, ctx->n_goff, true, false}));
   }
   return DGP_OK;
 }

@@ -78,6 +78,9 @@ hipError_t gauss_lik(hipStream_t st, const double* mean, const double* var, cons
 // fold dF into (mbar, vbar) of the producing layer; sums over s when dedup
 hipError_t fold_sample_grad(hipStream_t st, const double* Fbar, const double* var, long Nc, int S, int dedup, int D,
                             ZSource zsrc, long n_chunk0, double* mbar, double* vbar, double* acc_dkvar);
+// seeds of a vector-Jacobian product through the last layer: cotangents of (F, Fmean, Fvar), each [S, Ntot, D] or null
+hipError_t vjp_seed(hipStream_t st, const double* fbar, const double* meanbar, const double* varbar, const double* var,
+                    long Nc, int S, int dedup, int D, ZSource zsrc, long Ntot, long n_chunk0, double* mbar, double* vbar);
 hipError_t cbar_fix(hipStream_t st, double* Cbar, const double* mbar, const double* u, long P, int Mp, int D);
 hipError_t make_x1(hipStream_t st, const double* Xin, long x_row0, long P, int Din, double* X1);     // [X | 1]
 hipError_t xbar_finish(hipStream_t st, const double* R1, const double* X1, long P, const double* ls, int Din, int D,

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void fold_kernel(const double* __restrict__ Fb
     vbar[idx] = vb;
     dk += vb;
   }
-  block_atomic_add(dk, acc_dkvar, sh);
+  if (acc_dkvar) block_atomic_add(dk, acc_dkvar, sh);
 }
 
 hipError_t fold_sample_grad(hipStream_t st, const double* Fbar, const double* var, long Nc, int S, int dedup, int D,
@@ -263,6 +263,47 @@ hipError_t fold_sample_grad(hipStream_t st, const double* Fbar, const double* va
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Fbar, var, Nc, S, dedup, D, zsrc, n_chunk0,
                      mbar, vbar, acc_dkvar);
+  LAUNCH_CHECK();
+}
+
+// Seeds of the vector-Jacobian product through the last layer (acquisition side; reference: tf.GradientTape on x,
+// Infill_criteria.py:79-85).  With cotangents of the layer's sample F, mean and variance ([S, Ntot, D], any may be
+// null):  mbar = meanbar + Fbar,  vbar = varbar + Fbar z / (2 sqrt(var + eps));  summed over s for a single-layer model.
+__global__ __launch_bounds__(256) void vjp_seed_kernel(const double* __restrict__ fbar, const double* __restrict__ meanbar,
+                                                       const double* __restrict__ varbar, const double* __restrict__ var,
+                                                       long Nc, int S, int dedup, int D, ZSource zsrc, long Ntot,
+                                                       long n_chunk0, double* __restrict__ mbar, double* __restrict__ vbar) {
+  const long P = dedup ? Nc : (long)S * Nc;
+  const long total = P * D;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long p = idx / D;
+    const int d = (int)(idx % D);
+    const double inv = 0.5 / sqrt(var[idx] + kJitter);
+    double mb = 0.0, vb = 0.0;
+    const int s_lo = dedup ? 0 : (int)(p / Nc), s_hi = dedup ? S : s_lo + 1;
+    const long i = dedup ? p : p % Nc;
+    for (int s = s_lo; s < s_hi; ++s) {
+      const long src = ((long)s * Ntot + n_chunk0 + i) * D + d;
+      if (meanbar) mb += meanbar[src];
+      if (varbar) vb += varbar[src];
+      if (fbar) {
+        const double fb = fbar[src];
+        mb += fb;
+        vb += fb * draw_z(zsrc, s, n_chunk0 + i, d, D) * inv;
+      }
+    }
+    mbar[idx] = mb;
+    vbar[idx] = vb;
+  }
+}
+hipError_t vjp_seed(hipStream_t st, const double* fbar, const double* meanbar, const double* varbar, const double* var,
+                    long Nc, int S, int dedup, int D, ZSource zsrc, long Ntot, long n_chunk0, double* mbar, double* vbar) {
+  const long total = (dedup ? Nc : (long)S * Nc) * D;
+  if (total == 0) return hipSuccess;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(vjp_seed_kernel, dim3((unsigned)blocks), dim3(256), 0, st, fbar, meanbar, varbar, var, Nc, S, dedup, D,
+                     zsrc, Ntot, n_chunk0, mbar, vbar);
   LAUNCH_CHECK();
 }
 
@@ -330,7 +371,7 @@ __global__ __launch_bounds__(256) void xbar_finish_kernel(const double* __restri
       xbar[p * Din + j] = a;
     }
   }
-  block_atomic_add(x2, acc_x2rs + j, sh);
+  if (acc_x2rs) block_atomic_add(x2, acc_x2rs + j, sh);
 }
 hipError_t xbar_finish(hipStream_t st, const double* R1, const double* X1, long P, const double* ls, int Din, int D,
                        int mean_kind, const double* meanW, const double* mbar, int want_xbar, double* xbar,

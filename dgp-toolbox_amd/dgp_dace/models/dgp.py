@@ -128,6 +128,7 @@ class DGP_Base:
     def _next_seed(self):
         s = self.seed + self._eval_count
         self._eval_count += 1
+        self.last_seed = s          # the seed of the most recent evaluation (propagate_vjp replays it)
         return s
 
     # ------------------------------------------------------------------ forward API (dgp.py:34-124)
@@ -139,6 +140,18 @@ class DGP_Base:
         X = np.asarray(X.numpy() if hasattr(X, "numpy") else X, dtype=np.float64)
         Fs, Fm, Fv = ctx.propagate(X, int(S), self._next_seed(), zs)
         return [as_tensor(a) for a in Fs], [as_tensor(a) for a in Fm], [as_tensor(a) for a in Fv]
+
+    def propagate_vjp(self, X, S=1, f_bar=None, mean_bar=None, var_bar=None, zs=None, seed=None):
+        """Gradient with respect to X of  sum(f_bar*F_L) + sum(mean_bar*Fmean_L) + sum(var_bar*Fvar_L)  for the LAST
+        layer's outputs of `propagate(X, S=S)` ([S,N,D_L] cotangents, any may be None): the vector-Jacobian product
+        that the reference obtains from `tf.GradientTape` on x (Infill_criteria.py:79-85). The Monte-Carlo draws are
+        those of the forward evaluation being differentiated: pass the same `zs`, or `seed` (default: the seed of
+        the most recent forward call, `self.last_seed`). Returns [N, D]."""
+        ctx = self._sync_model()
+        X = np.asarray(X.numpy() if hasattr(X, "numpy") else X, dtype=np.float64)
+        if seed is None:
+            seed = getattr(self, "last_seed", self.seed)
+        return as_tensor(ctx.propagate_vjp(X, int(S), seed, zs, f_bar=f_bar, mean_bar=mean_bar, var_bar=var_bar))
 
     def predict_f(self, X, full_cov=False, S=1):
         if full_cov:

@@ -82,6 +82,15 @@ int dgp_elbo(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs, do
 int dgp_propagate(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
                   double* const* Fs, double* const* Fmeans, double* const* Fvars, int32_t add_lik_var);
 
+/* vector-Jacobian product of dgp_propagate with respect to Xnew: replaces `tape.gradient(objective, x)` on the
+ * acquisition side (Infill_criteria.py:79-85, where the objective is a function of predict_f / propagate outputs).
+ * f_bar, mean_bar, var_bar: cotangents of the LAST layer's sample F, Fmean and Fvar, host [S,Nn,D_out_L] each
+ * (any may be NULL = zero, at least one given; the likelihood variance that predict_y adds is constant in x).
+ * The same (seed | zs) as the forward call must be passed: the draws z are held fixed (reparameterisation,
+ * utils.py:40-41).  xbar_out: host [Nn, D_in] = sum over outputs of cotangent * d output / d Xnew.            */
+int dgp_propagate_vjp(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
+                      const double* f_bar, const double* mean_bar, const double* var_bar, double* xbar_out);
+
 /* ---- backward + optimisers: replaces the tf.GradientTape / Adam / NaturalGradient loop bodies
  *      (dgp.py:270-276, 326-345).  Split so that a multi-GPU host can all-reduce between the stages:
  *   dgp_grad_partial : this rank's sums over its data points (ELBO data term + every point-sum the

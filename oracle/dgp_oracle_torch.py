@@ -135,6 +135,28 @@ def elbo_and_grads(model, zs, S=None, data=None, chunk=None, P=None, want_grads=
     return elbo, G
 
 
+def propagate_vjp(model, X, zs, S, f_bar=None, mean_bar=None, var_bar=None):
+    """d/dX of  sum(f_bar*F_L) + sum(mean_bar*Fmean_L) + sum(var_bar*Fvar_L)  by autograd through the layer stack
+    with the draws zs held fixed -- what `tape.gradient(objective, x)` computes on the acquisition side
+    (Infill_criteria.py:79-85; propagate dgp.py:34-63).  Cotangents are [S,N,D_L] numpy arrays or None.
+    Returns (dX [N,D], F_L, Fmean_L, Fvar_L) as numpy."""
+    P = params_from_model(model)
+    Xt = torch.tensor(np.asarray(X, dtype=np.float64), dtype=DT, requires_grad=True)
+    N = Xt.shape[0]
+    F = Xt[None].expand(S, -1, -1).reshape(S * N, -1)
+    for layer, p, z in zip(model.layers, P["layers"], zs):
+        mean, var = conditional_ND(layer, p, F)
+        F = mean + torch.as_tensor(z, dtype=DT).reshape(S * N, -1) * (var + JITTER) ** 0.5
+    obj = 0.0
+    for bar, out in ((f_bar, F), (mean_bar, mean), (var_bar, var)):
+        if bar is not None:
+            obj = obj + (torch.as_tensor(np.asarray(bar), dtype=DT).reshape(S * N, -1) * out).sum()
+    obj.backward()
+    shp = (S, N, -1)
+    return (Xt.grad.numpy().copy(), F.detach().numpy().reshape(shp), mean.detach().numpy().reshape(shp),
+            var.detach().numpy().reshape(shp))
+
+
 # --------------------------------------------------------------------------------------
 # gpflow.optimizers.NaturalGradient (XiNat) by its own autodiff route  [ext]
 # --------------------------------------------------------------------------------------

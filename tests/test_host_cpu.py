@@ -185,3 +185,39 @@ def test_two_rank_gloo_sharding_reproduces_the_full_batch_sums(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "SHARDED_OK" in outs[0]
+
+
+def test_infill_host_math_without_a_device():
+    """Acquisition-side host logic (dgp_dace/Infill_criteria.py): EI partials, moment cotangents, DE restatement."""
+    from scipy.stats import norm
+    from dgp_dace import Infill_criteria as IC
+    rng = np.random.default_rng(0)
+    mean, var, y_min = rng.standard_normal((5, 1)), rng.uniform(0.2, 2.0, (5, 1)), 0.3
+    ei, d_mean, d_var = IC._ei(y_min, mean, var)
+    sd = np.sqrt(var)
+    # the reference's expression: (y_min - mu) cdf + var * N(mu, sd).prob(y_min)   (Infill_criteria.py:43-47)
+    want = (y_min - mean) * norm.cdf(y_min, mean, sd) + var * norm.pdf(y_min, mean, sd)
+    np.testing.assert_allclose(ei, want, rtol=1e-13)
+    h = 1e-6
+    np.testing.assert_allclose(d_mean, (IC._ei(y_min, mean + h, var)[0] - IC._ei(y_min, mean - h, var)[0]) / (2 * h), rtol=1e-7)
+    np.testing.assert_allclose(d_var, (IC._ei(y_min, mean, var + h)[0] - IC._ei(y_min, mean, var - h)[0]) / (2 * h), rtol=1e-7)
+    # cotangents of the per-sample moments: directional finite difference of sum(a*mean + b*var)
+    Fm, Fv = rng.standard_normal((7, 5, 1)), rng.uniform(0.1, 1.0, (7, 5, 1))
+    a, b = rng.standard_normal((5, 1)), rng.standard_normal((5, 1))
+    obj = lambda Fm, Fv: float(sum((c * m).sum() for c, m in zip((a, b), IC._moments(Fm, Fv))))
+    mb, vb = IC._moment_cotangents(Fm, Fm.mean(0), a, b)
+    dm, dv = rng.standard_normal(Fm.shape), rng.standard_normal(Fv.shape)
+    fd = (obj(Fm + h * dm, Fv + h * dv) - obj(Fm - h * dm, Fv - h * dv)) / (2 * h)
+    assert abs(fd - float((mb * dm).sum() + (vb * dv).sum())) < 1e-7 * max(1.0, abs(fd))
+    # differential evolution finds the minimum of a shifted quadratic, evaluating whole populations per call
+    calls = []
+    def f(U):
+        calls.append(U.shape)
+        return ((U - np.array([1.0, -2.0])) ** 2).sum(1)
+    u = IC._differential_evolution(f, np.zeros(2), 1.5, 40, 120, np.random.default_rng(1))
+    np.testing.assert_allclose(u, [1.0, -2.0], atol=1e-3)
+    assert all(c == (40, 2) for c in calls)
+    # only the DGP branch exists
+    class Gpr: name = 'gpr'
+    with pytest.raises(NotImplementedError):
+        IC.EI(0.0, 2).run(Gpr(), np.zeros((1, 2)))
