@@ -201,23 +201,27 @@ GemmArgs mk(long M, long N, long K, const double* A, long lda, const double* B, 
   return a;
 }
 
-// Runs independent per-layer chains of small kernels concurrently: layer i goes to side stream i % kSide with its
-// own scratch set; the destructor joins everything back into the context's stream (also on error returns).
+// Runs independent per-layer chains of small kernels concurrently on three workers: the context's own stream and
+// two side streams (the runtime gives this process few hardware queues: with three side streams two of them shared
+// one, and raising GPU_MAX_HW_QUEUES slowed every launch).  Item i goes to worker i % 3 with that worker's scratch
+// set; the destructor joins everything back into the context's stream (also on error returns).
 struct LayerFork {
   dgp_ctx* ctx;
   hipStream_t main;
   bool on;
   ProfScope ps;
+  int used = 0;
   LayerFork(dgp_ctx* c, int n_items) : ctx(c), main(c->st), on(c->use_side && n_items > 1), ps(c, 2, 0, 0) {
     if (!on) return;
+    used = n_items - 1 < dgp_ctx::kSide - 1 ? n_items - 1 : dgp_ctx::kSide - 1;     // side streams in use
     (void)hipEventRecord(c->ev_fork, main);
-    for (int i = 0; i < dgp_ctx::kSide && i < n_items; ++i) (void)hipStreamWaitEvent(c->side[i], c->ev_fork, 0);
-    used = n_items < dgp_ctx::kSide ? n_items : dgp_ctx::kSide;
+    for (int i = 0; i < used; ++i) (void)hipStreamWaitEvent(c->side[i], c->ev_fork, 0);
   }
   void use(int i) {
     if (!on) return;
-    ctx->st = ctx->side[i % dgp_ctx::kSide];
-    ctx->sm = ctx->smset[i % dgp_ctx::kSide];
+    const int w = i % dgp_ctx::kSide;
+    ctx->st = w == 0 ? main : ctx->side[w - 1];
+    ctx->sm = ctx->smset[w];
   }
   ~LayerFork() {
     if (!on) return;
@@ -228,7 +232,6 @@ struct LayerFork {
       (void)hipStreamWaitEvent(main, ctx->ev_join[i], 0);
     }
   }
-  int used = 0;
 };
 
 // Split-K factor for the reductions over points: all active workgroups of such a launch run equally long, so
@@ -940,8 +943,9 @@ int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out) {
     }
     HIPCHK(wbar_total(ctx->st, dW, y.Wcat, du, y.u, M, Mp, D));
     if (!y.d.white) {
-      RET(G(ctx, 2, GEMM_NT, Mp, Mp, DM, dW, DM, y.Wcat, DM, T1, Mp, 1.0, 0));
-      RET(G(ctx, 2, GEMM_NT, Mp, Mp, D, du, D, y.u, D, T1, Mp, 1.0, 1));
+      RET(G(ctx, 2, GEMM_NT, Mp, Mp, D, du, D, y.u, D, T1, Mp, 1.0, 0));
+      // K = D*Mp against an Mp x Mp output: split the reduction so that more than a handful of workgroups run
+      RET(G(ctx, 2, GEMM_NT, Mp, Mp, DM, dW, DM, y.Wcat, DM, T1, Mp, 1.0, 1, 1, 0, 0, 0, D > 1 ? D : 1));
       RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Linv, Mp, T1, Mp, T2, Mp, 1.0, 0));
       RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Linv, Mp, dW, DM, y.dLq, Mp, 1.0, 0, D, 0, Mp, MM));
       RET(G(ctx, 2, GEMM_TN, Mp, D, Mp, y.Linv, Mp, du, D, y.dqmu_p, D, 1.0, 0));

@@ -44,6 +44,8 @@ hipError_t rbf_kuu(hipStream_t st, const double* Z, const double* var, const dou
 constexpr int LEAF = 64;
 
 // One wave per matrix: thread i owns row i; the matrix lives in LDS, so a barrier is a single-wave s_barrier.
+// Global reads and writes go row by row with the lanes along the row (coalesced), and the dot products carry four
+// independent partial sums (the dependent fp64 FMA chain was the critical path of the one-wave kernel).
 __global__ __launch_bounds__(64) void leaf_potrf_inv_kernel(double* __restrict__ Aall, double* __restrict__ Xall, int ld,
                                                             long stride, int off, int n, int do_chol,
                                                             int* __restrict__ info) {
@@ -52,23 +54,34 @@ __global__ __launch_bounds__(64) void leaf_potrf_inv_kernel(double* __restrict__
   double* A = Aall + (long)blockIdx.x * stride + (long)off * ld + off;
   double* X = Xall + (long)blockIdx.x * stride + (long)off * ld + off;
   const int i = threadIdx.x;
-  if (i < n)
-    for (int c = 0; c < n; ++c) Ls[i][c] = (c <= i) ? A[(long)i * ld + c] : 0.0;
+  for (int r = 0; r < n; ++r) {
+    if (i < n) Ls[r][i] = (i <= r) ? A[(long)r * ld + i] : 0.0;
+    Xs[r][i] = 0.0;
+  }
   __syncthreads();
   if (do_chol) {
     // left-looking by columns: column c needs the finished columns 0..c-1 only -> one barrier per column
     for (int c = 0; c < n; ++c) {
       double v = 0.0;
       if (i >= c && i < n) {
-        v = Ls[i][c];
-        for (int k = 0; k < c; ++k) v -= Ls[i][k] * Ls[c][k];
+        double v0 = Ls[i][c], v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        int k = 0;
+        for (; k + 3 < c; k += 4) {
+          v0 -= Ls[i][k] * Ls[c][k];
+          v1 -= Ls[i][k + 1] * Ls[c][k + 1];
+          v2 -= Ls[i][k + 2] * Ls[c][k + 2];
+          v3 -= Ls[i][k + 3] * Ls[c][k + 3];
+        }
+        for (; k < c; ++k) v0 -= Ls[i][k] * Ls[c][k];
+        v = (v0 + v1) + (v2 + v3);
       }
       const double piv = __shfl(v, c);                 // pivot of this column (lane c)
+      const double rs = (piv > 0.0) ? 1.0 / sqrt(piv) : nan("");
       if (i == c) {
         if (!(piv > 0.0)) atomicOr(info, 1);
         Ls[c][c] = (piv > 0.0) ? sqrt(piv) : nan("");
       } else if (i > c && i < n) {
-        Ls[i][c] = v / ((piv > 0.0) ? sqrt(piv) : nan(""));
+        Ls[i][c] = v * rs;
       }
       __syncthreads();
     }
@@ -76,19 +89,25 @@ __global__ __launch_bounds__(64) void leaf_potrf_inv_kernel(double* __restrict__
   // inverse: thread j owns column j (forward substitution, everything in LDS)
   if (i < n) {
     const int j = i;
-    for (int r = 0; r < j; ++r) Xs[r][j] = 0.0;
     Xs[j][j] = 1.0 / Ls[j][j];
     for (int r = j + 1; r < n; ++r) {
-      double s = 0.0;
-      for (int k = j; k < r; ++k) s += Ls[r][k] * Xs[k][j];
-      Xs[r][j] = -s / Ls[r][r];
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int k = j;
+      for (; k + 3 < r; k += 4) {
+        s0 += Ls[r][k] * Xs[k][j];
+        s1 += Ls[r][k + 1] * Xs[k + 1][j];
+        s2 += Ls[r][k + 2] * Xs[k + 2][j];
+        s3 += Ls[r][k + 3] * Xs[k + 3][j];
+      }
+      for (; k < r; ++k) s0 += Ls[r][k] * Xs[k][j];
+      Xs[r][j] = -((s0 + s1) + (s2 + s3)) / Ls[r][r];
     }
   }
   __syncthreads();
-  if (i < n)
-    for (int c = 0; c < n; ++c) {
-      if (do_chol) A[(long)i * ld + c] = Ls[i][c];
-      X[(long)i * ld + c] = Xs[i][c];
+  for (int r = 0; r < n; ++r)
+    if (i < n) {
+      if (do_chol) A[(long)r * ld + i] = Ls[r][i];
+      X[(long)r * ld + i] = Xs[r][i];
     }
 }
 
@@ -429,37 +448,37 @@ hipError_t phi_tril_halfdiag(hipStream_t st, double* T, int Mp, int batch) {
 }
 
 // RBF backward through Kuu = K(Z,Z) + jitter*I with dKuu = sym(S)   
-__global__ void rbf_kuu_bwd_kernel(const double* __restrict__ S, const double* __restrict__ Kuu,
-                                   const double* __restrict__ Z, const double* __restrict__ var,
-                                   const double* __restrict__ ls, int M, int Mp, int Din, double* __restrict__ dZ,
-                                   double* __restrict__ dls, double* __restrict__ dvar) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
+__global__ __launch_bounds__(64) void rbf_kuu_bwd_kernel(const double* __restrict__ S, const double* __restrict__ Kuu,
+                                                         const double* __restrict__ Z, const double* __restrict__ var,
+                                                         const double* __restrict__ ls, int M, int Mp, int Din,
+                                                         double* __restrict__ dZ, double* __restrict__ dls,
+                                                         double* __restrict__ dvar) {
+  // one wave per (inducing point m, input dimension j): lanes stride over n, so rows of Kuu and S are read coalesced
+  const int m = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+  const double zm = Z[(long)m * Din + j], l = ls[j];
   double zacc = 0.0, lacc = 0.0, vacc = 0.0;
-  if (m < M) {
-    const double zm = Z[(long)m * Din + j], l = ls[j];
-    for (int n = 0; n < M; ++n) {
-      const double k0 = Kuu[(long)m * Mp + n] - (m == n ? kJitter : 0.0);
-      const double h = 0.5 * (S[(long)m * Mp + n] + S[(long)n * Mp + m]) * k0;
-      const double dl = zm - Z[(long)n * Din + j];
-      zacc += h * dl;
-      lacc += h * dl * dl;
-      vacc += h;
-    }
-    dZ[(long)m * Din + j] += -2.0 * zacc / (l * l);
+  for (int n = lane; n < M; n += 64) {
+    const double k0 = Kuu[(long)m * Mp + n] - (m == n ? kJitter : 0.0);
+    const double h = 0.5 * (S[(long)m * Mp + n] + S[(long)n * Mp + m]) * k0;
+    const double dl = zm - Z[(long)n * Din + j];
+    zacc += h * dl;
+    lacc += h * dl * dl;
+    vacc += h;
   }
-  // wave-reduce the scalar accumulators, one atomic per wave
-  for (int o = 32; o > 0; o >>= 1) { lacc += __shfl_down(lacc, o); vacc += __shfl_down(vacc, o); }
-  if ((threadIdx.x & 63) == 0) {
-    const double l = ls[j];
+  for (int o = 32; o > 0; o >>= 1) {
+    zacc += __shfl_down(zacc, o);
+    lacc += __shfl_down(lacc, o);
+    vacc += __shfl_down(vacc, o);
+  }
+  if (lane == 0) {
+    dZ[(long)m * Din + j] += -2.0 * zacc / (l * l);
     unsafeAtomicAdd(dls + j, lacc / (l * l * l));
     if (j == 0) unsafeAtomicAdd(dvar, vacc / var[0]);
   }
 }
 hipError_t rbf_kuu_bwd(hipStream_t st, const double* S, const double* Kuu, const double* Z, const double* var,
                        const double* ls, int M, int Mp, int Din, double* dZ, double* dls, double* dvar) {
-  hipLaunchKernelGGL(rbf_kuu_bwd_kernel, dim3((M + 255) / 256, Din), dim3(256), 0, st, S, Kuu, Z, var, ls, M, Mp, Din,
-                     dZ, dls, dvar);
+  hipLaunchKernelGGL(rbf_kuu_bwd_kernel, dim3(M, Din), dim3(64), 0, st, S, Kuu, Z, var, ls, M, Mp, Din, dZ, dls, dvar);
   LAUNCH_CHECK();
 }
 
