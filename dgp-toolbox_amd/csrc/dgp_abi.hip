@@ -33,7 +33,9 @@ struct Layer {
   long off_Z, off_var, off_ls, off_qmu, off_qsqrt;   // offsets in the flat parameter vector
   double *meanW = nullptr, *meanb = nullptr;
   double *Kuu, *Lu, *Linv, *Lq, *qmu_p, *Wcat, *u;   // derived small matrices (padded to Mp)
-  double *Scat;                                      // [D*Mp x Mp]: S'_d = W_d W_d^T - I stacked (backward only)
+  double *Scat;                                      // [D*Mp x Mp] (backward only): W_d^T stacked when t_d is kept from the
+                                                     // forward pass (ctx->store_t), else S'_d = W_d W_d^T - I stacked
+  double *Tt = nullptr;                              // [points][D*Mp]: t_d = W_d^T c (training chunks, ctx->store_t)
   double *Z1;                                        // [Mp x (D_in+1)] = [Z | 1]
   double *dLq, *dqmu_p;                              // d ELBO / d (Lq, q_mu) of the last grad_finish
   long acc_Q, acc_G, acc_du, acc_GX, acc_x2, acc_dvar;
@@ -86,6 +88,11 @@ struct dgp_ctx {
   hipStream_t side[kSide] = {nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr};
   bool use_side = true;
+  // Option (DGP_STORE_T=1): keep t_d = W_d^T c from the forward pass (16 KB/point/layer at D=8, M=256), so that dC
+  // needs only the triangular products W_d t_d instead of the dense S'_d c.  Measured at config 2: the dC product
+  // 19.2 -> 15.7 ms (it now streams 16 GB, re-read per column tile), the T-product 12.0 -> 15.1 ms (the 16 GB store):
+  // no net gain, +32 GB of HBM traffic per iteration -> off by default.
+  bool store_t = false;
   std::vector<double*> zs_dev;
   std::vector<size_t> zs_cap;
   double* Xnew = nullptr;
@@ -352,6 +359,7 @@ size_t carve(dgp_ctx* ctx, char* base, long Nc, int S, bool train) {
     y.F = take((long)S * Nc * D);
     if (train) { y.mbar = take(Pl * D); y.vbar = take(Pl * D); }
     else { y.mbar = y.vbar = nullptr; }
+    y.Tt = (train && ctx->store_t) ? take(Pl * D * y.Mp) : nullptr;
   }
   if (train) {
     ctx->Cbar = take(Pmax_Mp); ctx->Kbar = take(Pmax_Mp); ctx->Gt = take(Pmax_Mp); ctx->xbar = take(xb_max);
@@ -413,11 +421,15 @@ int prep(dgp_ctx* ctx, bool train = false) {
       RET(G(ctx, 2, GEMM_NN, Mp, D, Mp, y.Linv, Mp, y.qmu_p, D, y.u, D, 1.0, 0));
     }
     HIPCHK(layer_kl(ctx->st, y.Wcat, y.u, y.Lq, y.Lu, M, Mp, D, y.d.white, ctx->scal));
-    if (train) {   // S'_d = W_d W_d^T - I  (symmetric), stacked [D*Mp x Mp]
-      GemmArgs a = mk(Mp, Mp, Mp, y.Wcat, (long)D * Mp, y.Wcat, (long)D * Mp, y.Scat, Mp);
-      a.batch = D; a.sA = Mp; a.sB = Mp; a.sC = MM;
-      RET(GX(ctx, 2, GEMM_NT, a));
-      HIPCHK(sub_identity(ctx->st, y.Scat, M, Mp, D));
+    if (train) {
+      if (ctx->store_t) {
+        HIPCHK(wcat_transpose(ctx->st, y.Wcat, Mp, D, y.Scat));
+      } else {       // S'_d = W_d W_d^T - I  (symmetric), stacked [D*Mp x Mp]
+        GemmArgs a = mk(Mp, Mp, Mp, y.Wcat, (long)D * Mp, y.Wcat, (long)D * Mp, y.Scat, Mp);
+        a.batch = D; a.sA = Mp; a.sB = Mp; a.sC = MM;
+        RET(GX(ctx, 2, GEMM_NT, a));
+        HIPCHK(sub_identity(ctx->st, y.Scat, M, Mp, D));
+      }
       HIPCHK(make_z1(ctx->st, P(ctx, y.off_Z), M, Mp, Din, y.Z1));
     }
   }
@@ -456,10 +468,10 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
       a.tri = TRI_B_UPPER; a.triblk = Mp; a.epi = 2; a.rowsq = y.cnp; a.rowsq_ld = Pl;
       RET(GX(ctx, 0, GEMM_NT, a, tri1, (double)Pl * Mp * 16));
     }
-    {  // t_d = W_d^T c is never stored: only |t_d|^2 partials leave the kernel
-      GemmArgs a = mk(Pl, (long)D * Mp, Mp, y.Ct, Mp, y.Wcat, (long)D * Mp, nullptr, (long)D * Mp);
-      a.tri = TRI_B_LOWER; a.triblk = Mp; a.epi = 1; a.rowsq = y.tnp; a.rowsq_ld = Pl;
-      RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 8));
+    {  // t_d = W_d^T c: |t_d|^2 partials always leave the kernel; t_d itself only for the backward pass (store_t)
+      GemmArgs a = mk(Pl, (long)D * Mp, Mp, y.Ct, Mp, y.Wcat, (long)D * Mp, y.Tt, (long)D * Mp);
+      a.tri = TRI_B_LOWER; a.triblk = Mp; a.epi = y.Tt ? 2 : 1; a.rowsq = y.tnp; a.rowsq_ld = Pl;
+      RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 8 * (y.Tt ? 1 + D : 1)));
     }
     RET(GX(ctx, 0, GEMM_NN, mk(Pl, D, Mp, y.Ct, Mp, y.u, D, y.mean0, D), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
     {
@@ -496,7 +508,14 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     const long row0 = dedup ? n0 : 0;
     const long DM = (long)D * Mp, MM = (long)Mp * Mp;
     const double tri1 = (double)Pl * Mp * (Mp + 1.0);
-    {  // dC = sum_d 2 vbar_d .* (C S'_d)      (A operand scaled on the fly; K = D*Mp re-reads C per block)
+    if (y.Tt) {  // dC = sum_d 2 vbar_d (W_d t_d - c): [2 vbar .* T] * WTcat, W_d lower => k <= n per block; "- c" in the epilogue
+      GemmArgs a = mk(Pl, Mp, DM, y.Tt, DM, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);
+      a.ascale = y.vbar; a.as_ld = D; a.a_kblk = Mp; a.ascale_mode = 1; a.a_wrap = 0;
+      a.tri = TRI_B_UPPER; a.triblk = Mp;
+      a.eadd = y.Ct; a.eadd_nsc = D;
+      a.rowf = y.mbar; a.colf = y.u; a.rank = D;             // + mbar u^T in the epilogue
+      RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 8 * (2 + D)));
+    } else {  // dC = sum_d 2 vbar_d .* (C S'_d)      (A operand scaled on the fly; K = D*Mp re-reads C per block)
       GemmArgs a = mk(Pl, Mp, DM, y.Ct, Mp, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);
       a.ascale = y.vbar; a.as_ld = D; a.a_kblk = Mp; a.ascale_mode = 1;
       a.rowf = y.mbar; a.colf = y.u; a.rank = D;             // + mbar u^T in the epilogue
@@ -598,6 +617,8 @@ int dgp_create(int device, void* hip_stream, dgp_ctx** out) {
   {
     const char* e = getenv("DGP_SIDE_STREAMS");
     ctx->use_side = !(e && e[0] == '0');
+    const char* t = getenv("DGP_STORE_T");
+    ctx->store_t = t && t[0] == '1';
     bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < dgp_ctx::kSide && ok; ++i)
       ok = hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) == hipSuccess &&

@@ -47,6 +47,7 @@ hipError_t natgrad_mu(hipStream_t st, const double* Sn, const double* g_qmu_p, d
 hipError_t make_z1(hipStream_t st, const double* Z, int M, int Mp, int Din, double* Z1);
 hipError_t rbf_kuf_bwd_finish(hipStream_t st, const double* GX, const double* x2rs, const double* vsum, const double* Z,
                               const double* var, const double* ls, int M, int Din, double* dZ, double* dls, double* dvar);
+hipError_t wcat_transpose(hipStream_t st, const double* Wcat, int Mp, int D, double* WT);
 hipError_t sub_identity(hipStream_t st, double* S, int M, int Mp, int batch);
 hipError_t symmetrize_lower(hipStream_t st, double* G, int Mp, int batch);
 hipError_t sub_scalars(hipStream_t st, const double* a, const double* b, double* out);   // out = a - b

@@ -66,10 +66,14 @@ struct GemmArgs {
   // optional row scaling of the physical A tile (fused elementwise work, no extra HBM pass):
   //   ascale_mode 1 (A not transposed): A[m][k] = ascale[m*as_ld + k / a_kblk] * Aphys[m][k % a_kblk]
   //                                     (K = nblk * a_kblk re-reads the same physical columns per block)
+  //                                     a_wrap = 0: A is stored with all K columns (no re-reading): A[m][k] =
+  //                                     ascale[m*as_ld + k / a_kblk] * Aphys[m][k]; with a triangular hint the
+  //                                     host passes triblk == a_kblk (scale blocks = triangular blocks)
   //   ascale_mode 2 (A transposed):     A[k][m] = ascale[k*as_ld + batch] * Aphys[k][m]
   const double* ascale = nullptr;
   long as_ld = 0, a_kblk = 1;
   int ascale_mode = 0;
+  int a_wrap = 1;
   // epilogue: 0 store C; 1 only row sums of squares; 2 both.  rowsq[(tile_col*WC + wave_col)*rowsq_ld + row]
   int epi = 0;
   double* rowsq = nullptr;
@@ -78,6 +82,10 @@ struct GemmArgs {
   const double* rowf = nullptr;
   const double* colf = nullptr;
   int rank = 0;
+  // optional epilogue term (ascale_mode 1): C[m][n] -= alpha * (sum_{q < eadd_nsc} ascale[m*as_ld + q]) * eadd[m][n]
+  // (same leading dimension as C; fuses the "- c" of  dC = sum_d 2 vbar_d (W_d t_d - c))
+  const double* eadd = nullptr;
+  int eadd_nsc = 0;
   // optional second output C2 = (alpha * A B) .* E  (same shape / leading dimension as C; used for g = dK .* K)
   const double* emul = nullptr;
   double* C2 = nullptr;
@@ -266,9 +274,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       else
         tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, k0, m0, kend, g.M, tid);
     } else {
-      if (g.ascale_mode == 1) {                            // BK divides a_kblk: a k-tile never straddles blocks
+      if (g.ascale_mode == 1 && g.a_wrap) {                // BK divides a_kblk: a k-tile never straddles blocks
         tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, m0, cur_aoff, g.M, g.a_kblk, tid,
                                                                                       g.ascale, g.as_ld, cur_ablk);
+      } else if (g.ascale_mode == 1) {                     // all K columns stored; scale block = k0 / a_kblk
+        const long sblk = (nkb > 1 || g.tri == TRI_B_UPPER || g.tri == TRI_B_LOWER) ? cur_kb : cur_ablk;
+        tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, m0, k0, g.M, kend, tid,
+                                                                                      g.ascale, g.as_ld, sblk);
       } else {
         tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, m0, k0, g.M, kend, tid);
       }
@@ -433,7 +445,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     static_assert(!FAST || (VA == 2 && VB == 2), "fast path is vectorised");
     const int a_tr = tid / Cfg::A_TPR, a_tc = (tid % Cfg::A_TPR) * 2;
     const int b_tr = tid / Cfg::B_TPR, b_tc = (tid % Cfg::B_TPR) * 2;
-    const bool wrap = (!TA) && SCALED;                         // ascale_mode 1: K wraps around a_kblk physical columns
+    const bool wrap = (!TA) && SCALED && g.a_wrap;             // ascale_mode 1: K wraps around a_kblk physical columns
+    const bool blk_scale = (!TA) && SCALED && !g.a_wrap;       // ... or A holds all K columns: the scale follows the k-blocks
     // Addressing: one wave-uniform base pointer per operand (scalar registers, advanced per k-tile) plus constant
     // 32-bit per-lane byte offsets, so that the loads use the scalar-base form and no 64-bit vector adds.
     const char* ua = reinterpret_cast<const char*>(TA ? A + klo * g.lda + m0 : A + m0 * g.lda + (wrap ? 0 : klo));
@@ -477,6 +490,10 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       long ka = BK, kbs = BK;
       kk_in_blk += 1;
       if (kk_in_blk == ktiles_per_blk) { kk_in_blk = 0; ka = jump; kbs = jump; }
+      if (blk_scale) {             // scale blocks = triangular blocks when a hint is given, else every a_kblk columns
+        kk_in_wrap += 1;
+        if (nkb > 1 ? kk_in_blk == 0 : kk_in_wrap == g.a_kblk / BK) { kk_in_wrap = 0; if constexpr (SCALED) us += 8; }
+      }
       if (wrap) {
         kk_in_wrap += 1;
         if (kk_in_wrap == tiles_per_wrap) { kk_in_wrap = 0; ka = BK - g.a_kblk; if constexpr (SCALED) us += 8; }
@@ -548,6 +565,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   const bool atomic = g.splits > 1;
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
+    double esc = 0.0;
+    if (g.eadd != nullptr) {
+      const long row = m0 + (long)(i * WR + wr) * 16 + 4 * (li >> 2) + lk;
+      if (row < g.M)
+        for (int q = 0; q < g.eadd_nsc; ++q) esc += g.ascale[row * g.as_ld + q];
+      esc *= g.alpha;
+    }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const long row = m0 + (long)(i * WR + wr) * 16 + 4 * (li >> 2) + lk;
@@ -562,6 +586,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
             const double* cf = g.colf + col * g.rank;
             for (int q = 0; q < g.rank; ++q) v += rf[q] * cf[q];
           }
+          if (g.eadd != nullptr) v -= esc * g.eadd[row * g.ldc + col];
           if (atomic) unsafeAtomicAdd(p, v);
           else if (g.beta) *p += v;
           else *p = v;

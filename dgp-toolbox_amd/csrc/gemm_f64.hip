@@ -47,7 +47,7 @@ static inline bool vec2_ok(const double* p, long ld, long extent, long bstride, 
 // generic (predicated) path for any shape
 template <bool TA, bool TB>
 static hipError_t launch_generic(hipStream_t st, const GemmArgs& a) {
-  const bool va = vec2_ok(a.A, a.lda, TA ? a.M : (a.ascale_mode == 1 ? a.a_kblk : a.K), a.sA, a.batch);
+  const bool va = vec2_ok(a.A, a.lda, TA ? a.M : ((a.ascale_mode == 1 && a.a_wrap) ? a.a_kblk : a.K), a.sA, a.batch);
   const bool vb = vec2_ok(a.B, a.ldb, TB ? a.K : a.N, a.sB, a.batch);
   if (a.N > 16) {
     if (va && vb) return launch<TA, TB, 128, 64, 16, 2, 2, 2, 2>(st, a);
@@ -68,11 +68,12 @@ static hipError_t launch_fast(hipStream_t st, const GemmArgs& a) {
 template <bool TA, bool TB>
 static hipError_t dispatch(hipStream_t st, const GemmArgs& a) {
   constexpr long BM = 128, BN = 64, BK = 16;
-  const bool va = vec2_ok(a.A, a.lda, TA ? a.M : (a.ascale_mode == 1 ? a.a_kblk : a.K), a.sA, a.batch);
+  const bool va = vec2_ok(a.A, a.lda, TA ? a.M : ((a.ascale_mode == 1 && a.a_wrap) ? a.a_kblk : a.K), a.sA, a.batch);
   const bool vb = vec2_ok(a.B, a.ldb, TB ? a.K : a.N, a.sB, a.batch);
   bool fast = va && vb && a.N > 16 && a.N % BN == 0 && (a.tri == TRI_NONE || (a.triblk % BN == 0 && a.triblk % BK == 0)) &&
               (a.ascale_mode != 1 || (!TA && a.a_kblk % BK == 0 && a.K % a.a_kblk == 0)) && (a.ascale_mode != 2 || TA) &&
-              !(TB && a.ascale_mode != 0);
+              !(TB && a.ascale_mode != 0) &&
+              !(a.ascale_mode == 1 && !a.a_wrap && a.tri != TRI_NONE && a.triblk != a.a_kblk);
   const long Mf = (a.M / BM) * BM;
   if (!TA && a.K % BK != 0) fast = false;        // K is the contiguous direction of A: no K tail handling there
   const long Kf = TA ? (a.K / BK) * BK : a.K;
@@ -103,6 +104,7 @@ static hipError_t dispatch(hipStream_t st, const GemmArgs& a) {
     if (a.C) r.C = a.C + Mf * a.ldc;
     if (a.C2) { r.C2 = a.C2 + Mf * a.ldc; r.emul = a.emul + Mf * a.ldc; }
     if (a.rank > 0) r.rowf = a.rowf + Mf * a.rank;
+    if (a.eadd) r.eadd = a.eadd + Mf * a.ldc;
     if (a.rowsq) r.rowsq = a.rowsq + Mf;
     if (a.ascale_mode == 1) r.ascale = a.ascale + Mf * a.as_ld;
     if ((e = launch_generic<TA, TB>(st, r)) != hipSuccess) return e;

@@ -302,6 +302,22 @@ hipError_t rbf_kuf_bwd_finish(hipStream_t st, const double* GX, const double* x2
   LAUNCH_CHECK();
 }
 
+// WT[(d*Mp + j)*Mp + i] = Wcat[i*(D*Mp) + d*Mp + j]: the W_d^T stacked vertically ([D*Mp x Mp]), the B operand of
+// dC = [2 vbar .* T] * WTcat when t_d = W_d^T c is kept from the forward pass
+__global__ void wcat_transpose_kernel(const double* __restrict__ Wcat, int Mp, int D, double* __restrict__ WT) {
+  __shared__ double tile[32][33];
+  const int d = blockIdx.z;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = Wcat[(long)(i0 + r) * D * Mp + (long)d * Mp + j0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) WT[((long)d * Mp + j0 + r) * Mp + i0 + tx] = tile[tx][r];
+}
+hipError_t wcat_transpose(hipStream_t st, const double* Wcat, int Mp, int D, double* WT) {
+  hipLaunchKernelGGL(wcat_transpose_kernel, dim3(Mp / 32, Mp / 32, D), dim3(256), 0, st, Wcat, Mp, D, WT);
+  LAUNCH_CHECK();
+}
+
 __global__ void sub_identity_kernel(double* __restrict__ S, int M, int Mp, long total) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;

@@ -484,3 +484,21 @@ def test_infill_optimize_de_then_adam_improves_the_criterion():
     ref = np.asarray(c.run(m, rng.uniform(lo, hi, (64, d)), **kw))
     best = float(np.asarray(c.run(m, x_opt.reshape(1, d), **kw)).sum())
     assert best <= np.median(ref)            # minus-EI at the optimum beats a typical random candidate
+
+
+def test_stored_t_formulation_gives_the_same_gradient(monkeypatch):
+    """DGP_STORE_T=1 keeps t_d = W_d^T c from the forward pass and forms dC from triangular products (non-wrapping
+    scaled A operand, per-block triangular k-ranges, "- c" epilogue term of the GEMM engine): same gradient."""
+    g = load(CASES[1])
+    nl = n_layers(g)
+    zs = [g[f"zs{i}"] for i in range(nl)]
+    grads = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DGP_STORE_T", flag)
+        m = product_from_golden(g)
+        ctx = m._sync_model()
+        m._sync_data(m.data)
+        ctx.grad_partial(int(g["S"]), 0, zs)
+        ctx.grad_finish()
+        grads.append(ctx.grad_get())
+    _close(grads[1], grads[0], rtol=0, atol=1e-10 * np.abs(grads[0]).max())
