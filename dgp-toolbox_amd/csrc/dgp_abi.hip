@@ -36,6 +36,9 @@ struct Layer {
   double *Scat;                                      // [D*Mp x Mp] (backward only): W_d^T stacked when t_d is kept from the
                                                      // forward pass (ctx->store_t), else S'_d = W_d W_d^T - I stacked
   double *Tt = nullptr;                              // [points][D*Mp]: t_d = W_d^T c (training chunks, ctx->store_t)
+  double *Et = nullptr;                              // [points][Mp]: -2 dk/d(r2) of Kuf (training chunks, Matern kernels)
+  double *Euu = nullptr;                             // [Mp x Mp]: the same for Kuu (Matern kernels)
+  double *kdot = nullptr;                            // device scalar: sum_p dk_p . k_p (Matern kernels)
   double *Z1;                                        // [Mp x (D_in+1)] = [Z | 1]
   double *dLq, *dqmu_p;                              // d ELBO / d (Lq, q_mu) of the last grad_finish
   long acc_Q, acc_G, acc_du, acc_GX, acc_x2, acc_dvar;
@@ -308,7 +311,7 @@ int grow(dgp_ctx* ctx, double** p, size_t* cap, size_t n) {
 void free_model(dgp_ctx* ctx) {
   for (auto& l : ctx->L) {
     dev_free(l.Kuu); dev_free(l.Lu); dev_free(l.Linv); dev_free(l.Lq); dev_free(l.qmu_p); dev_free(l.Wcat);
-    dev_free(l.u); dev_free(l.Scat); dev_free(l.Z1); dev_free(l.dLq); dev_free(l.dqmu_p);
+    dev_free(l.u); dev_free(l.Scat); dev_free(l.Z1); dev_free(l.Euu); dev_free(l.kdot); dev_free(l.dLq); dev_free(l.dqmu_p);
   }
   ctx->L.clear();
   dev_free(ctx->params); dev_free(ctx->grad); dev_free(ctx->adam_m); dev_free(ctx->adam_v);
@@ -360,6 +363,7 @@ size_t carve(dgp_ctx* ctx, char* base, long Nc, int S, bool train) {
     if (train) { y.mbar = take(Pl * D); y.vbar = take(Pl * D); }
     else { y.mbar = y.vbar = nullptr; }
     y.Tt = (train && ctx->store_t) ? take(Pl * D * y.Mp) : nullptr;
+    y.Et = (train && y.d.kernel_kind != DGP_KERNEL_RBF) ? take(Pl * y.Mp) : nullptr;
   }
   if (train) {
     ctx->Cbar = take(Pmax_Mp); ctx->Kbar = take(Pmax_Mp); ctx->Gt = take(Pmax_Mp); ctx->xbar = take(xb_max);
@@ -410,7 +414,8 @@ int prep(dgp_ctx* ctx, bool train = false) {
     const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
     const long MM = (long)Mp * Mp;
     HIPCHK(pack_q(ctx->st, P(ctx, y.off_qsqrt), P(ctx, y.off_qmu), M, Mp, D, y.Lq, y.qmu_p));
-    HIPCHK(rbf_kuu(ctx->st, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din, y.Kuu));
+    HIPCHK(rbf_kuu(ctx->st, y.d.kernel_kind, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din, y.Kuu,
+                   train ? y.Euu : nullptr));
     HIPCHK(copy_mat(ctx->st, y.Kuu, y.Lu, MM));
     HIPCHK(potrf_inv(ctx->st, y.Lu, y.Linv, ctx->sm[9], Mp, 1, ctx->info));
     if (y.d.white) {
@@ -460,7 +465,8 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
     const int nplane = Mp / 32;
     {
       ProfScope ps(ctx, 1, 0, (double)Pl * (Mp + Din) * 8);
-      HIPCHK(rbf_kuf(ctx->st, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din, y.Kt));
+      HIPCHK(rbf_kuf(ctx->st, y.d.kernel_kind, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
+                     y.Kt, y.Et));
     }
     const double tri1 = (double)Pl * Mp * (Mp + 1.0);   // 2 * M(M+1)/2 flops per point
     {  // c = Lu^-1 k  and |c|^2 partials
@@ -525,7 +531,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     {
       GemmArgs a = mk(Pl, Mp, Mp, ctx->Cbar, Mp, y.Linv, Mp, ctx->Kbar, Mp);
       a.tri = TRI_B_LOWER; a.triblk = Mp;
-      a.emul = y.Kt; a.C2 = ctx->Gt;                        // g = dK .* K for the RBF backward
+      a.emul = y.Et ? y.Et : y.Kt; a.C2 = ctx->Gt;          // g = dK .* e (e = -2 dk/dr2; = k for the squared exponential)
       RET(GX(ctx, 0, GEMM_NN, a, tri1, (double)Pl * Mp * 32));
     }
     // reductions over the chunk's points (accumulate into the all-reduce buffer)
@@ -673,7 +679,7 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
   int Mpmax = 0, Dmax = 0;
   for (int l = 0; l < n_layers; ++l) {
     const dgp_layer_desc& d = layers[l];
-    if (d.D_in <= 0 || d.D_in > 64 || d.D_out <= 0 || d.M <= 0 || d.M > 1024 || d.D_out > 65535 || d.kernel_kind != DGP_KERNEL_RBF ||
+    if (d.D_in <= 0 || d.D_in > 64 || d.D_out <= 0 || d.M <= 0 || d.M > 1024 || d.D_out > 65535 || d.kernel_kind < DGP_KERNEL_RBF || d.kernel_kind > DGP_KERNEL_MATERN52 ||
         d.mean_kind < 0 || d.mean_kind > 2)
       return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: unsupported layer description (RBF kernel, M <= 1024, D_in <= 64)");
     if (l > 0 && d.D_in != layers[l - 1].D_out) return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: layer dims do not chain");
@@ -730,6 +736,7 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
     RET(dev_alloc(ctx, &y.Kuu, MM)); RET(dev_alloc(ctx, &y.Lu, MM)); RET(dev_alloc(ctx, &y.Linv, MM));
     RET(dev_alloc(ctx, &y.Lq, MM * D)); RET(dev_alloc(ctx, &y.qmu_p, (long)y.Mp * D));
     RET(dev_alloc(ctx, &y.Wcat, MM * D)); RET(dev_alloc(ctx, &y.u, (long)y.Mp * D)); RET(dev_alloc(ctx, &y.Scat, MM * D)); RET(dev_alloc(ctx, &y.Z1, (long)y.Mp * (y.d.D_in + 1)));
+    if (y.d.kernel_kind != DGP_KERNEL_RBF) { RET(dev_alloc(ctx, &y.Euu, MM)); RET(dev_alloc(ctx, &y.kdot, 1)); }
     RET(dev_alloc(ctx, &y.dLq, MM * D)); RET(dev_alloc(ctx, &y.dqmu_p, (long)y.Mp * D));
     if (y.d.mean_kind == DGP_MEAN_LINEAR) {
       y.meanW = ctx->mean_params + moff; moff += (long)y.d.D_in * D;
@@ -963,6 +970,7 @@ int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out) {
       RET(GX(ctx, 2, GEMM_NN, a));
     }
     HIPCHK(wbar_total(ctx->st, dW, y.Wcat, du, y.u, M, Mp, D));
+    if (y.kdot) HIPCHK(lower_dot(ctx->st, y.Lu, Q, M, Mp, y.kdot));      // before Q is overwritten below
     if (!y.d.white) {
       RET(G(ctx, 2, GEMM_NT, Mp, Mp, D, du, D, y.u, D, T1, Mp, 1.0, 0));
       // K = D*Mp against an Mp x Mp output: split the reduction so that more than a handful of workgroups run
@@ -986,8 +994,8 @@ int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out) {
     RET(G(ctx, 2, GEMM_NN, Mp, Mp, Mp, T3, Mp, y.Linv, Mp, T4, Mp, 1.0, 0));
     RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Linv, Mp, T4, Mp, Sm, Mp, 1.0, 0));
     HIPCHK(rbf_kuf_bwd_finish(ctx->st, acc + y.acc_GX, acc + y.acc_x2, acc + y.acc_dvar, P(ctx, y.off_Z), P(ctx, y.off_var),
-                              P(ctx, y.off_ls), M, Din, g + y.off_Z, g + y.off_ls, g + y.off_var));
-    HIPCHK(rbf_kuu_bwd(ctx->st, Sm, y.Kuu, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
+                              P(ctx, y.off_ls), M, Din, g + y.off_Z, g + y.off_ls, g + y.off_var, y.kdot));
+    HIPCHK(rbf_kuu_bwd(ctx->st, Sm, y.Kuu, y.Euu, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
                        g + y.off_Z, g + y.off_ls, g + y.off_var));
     HIPCHK(unpack_q_grads(ctx->st, y.dLq, y.dqmu_p, M, Mp, D, g + y.off_qsqrt, g + y.off_qmu));
   }

@@ -8,12 +8,33 @@
 namespace dgp {
 
 constexpr double kJitter = 1e-6;        // gpflow.default_jitter()  (layers.py:222,230; utils.py:41)
+
+// Stationary kernels as functions of r2 = |(x - z)/l|^2 (kind = dgp_kernel_kind): value k and e = -2 dk/d(r2), the
+// factor every input/inducing-point/lengthscale gradient carries (for the squared exponential e = k).
+//   SquaredExponential  k = s2 exp(-r2/2)
+//   Matern32            k = s2 (1 + sqrt3 r) exp(-sqrt3 r),             r = sqrt(max(r2, 1e-36))   (gpflow K_r)
+//   Matern52            k = s2 (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r)
+// Below the clamp the gradient of r with respect to r2 is zero, as in the reference's autodiff.
+__device__ __forceinline__ void stationary_k(int kind, double s2, double r2, double& k, double& e) {
+  if (kind == 0) { k = s2 * exp(-0.5 * r2); e = k; return; }
+  const bool clamped = r2 < 1e-36;
+  const double r = sqrt(clamped ? 1e-36 : r2);
+  if (kind == 1) {
+    const double a = 1.7320508075688772 * r, ex = exp(-a);
+    k = s2 * (1.0 + a) * ex;
+    e = clamped ? 0.0 : 3.0 * s2 * ex;
+  } else {
+    const double a = 2.23606797749979 * r, ex = exp(-a);
+    k = s2 * (1.0 + a + (5.0 / 3.0) * r * r) * ex;
+    e = clamped ? 0.0 : (5.0 / 3.0) * s2 * (1.0 + a) * ex;
+  }
+}
 constexpr double kLikVarLower = 1e-6;   // gpflow Gaussian variance lower bound ("Softplus + Shift")
 
 // ---------------------------------------------------------------- small matrices (smallmat.hip)
 // All matrices are row-major [Mp x Mp] with leading dimension Mp, batched with stride Mp*Mp.
-hipError_t rbf_kuu(hipStream_t st, const double* Z, const double* var, const double* ls, int M, int Mp, int Din,
-                   double* Kuu /* + jitter*I, identity on the padding */);
+hipError_t rbf_kuu(hipStream_t st, int kind, const double* Z, const double* var, const double* ls, int M, int Mp, int Din,
+                   double* Kuu /* + jitter*I, identity on the padding */, double* Euu /* e factors, or null */);
 // A <- chol(A) (lower, upper zeroed) and X <- A^-1 of the factor; tmp = scratch [batch x Mp x Mp]; info: device flag set on non-PD
 hipError_t potrf_inv(hipStream_t st, double* A, double* X, double* tmp, int Mp, int batch, int* info);
 hipError_t trinv_lower(hipStream_t st, const double* L, double* X, double* tmp, int Mp, int batch);
@@ -33,7 +54,8 @@ hipError_t lqbar_finish(hipStream_t st, double* dLq, const double* Lq, int M, in
 hipError_t lubar_finish(hipStream_t st, double* dLu /* in: Q (+T2) */, const double* T2_or_null, const double* Lu,
                         int M, int Mp, int D, int white);                   // -tril(Q+T2) - D diag(1/Lu)
 hipError_t phi_tril_halfdiag(hipStream_t st, double* T, int Mp, int batch);
-hipError_t rbf_kuu_bwd(hipStream_t st, const double* S /* unsymmetrised dKuu */, const double* Kuu, const double* Z,
+hipError_t rbf_kuu_bwd(hipStream_t st, const double* S /* unsymmetrised dKuu */, const double* Kuu,
+                       const double* Euu /* null: squared exponential, e = k */, const double* Z,
                        const double* var, const double* ls, int M, int Mp, int Din, double* dZ, double* dls,
                        double* dvar);
 hipError_t unpack_q_grads(hipStream_t st, const double* dLq, const double* dqmu_p, int M, int Mp, int D,
@@ -46,7 +68,11 @@ hipError_t natgrad_mu(hipStream_t st, const double* Sn, const double* g_qmu_p, d
 // Z1 = [Z | 1] padded to Mp rows; and the Kuf part of dZ / dls / dvar from GX = g^T [X | 1] and sum_p x^2 rs
 hipError_t make_z1(hipStream_t st, const double* Z, int M, int Mp, int Din, double* Z1);
 hipError_t rbf_kuf_bwd_finish(hipStream_t st, const double* GX, const double* x2rs, const double* vsum, const double* Z,
-                              const double* var, const double* ls, int M, int Din, double* dZ, double* dls, double* dvar);
+                              const double* var, const double* ls, int M, int Din, double* dZ, double* dls, double* dvar,
+                              const double* kdot /* null: sum k.dK = column sums of g (e = k); else that sum */);
+// out[0] = sum_{i >= j} Lu[i][j] Q[i][j] = sum_p dk_p . k_p  (k = Lu c, Q = sum_p dk_p c_p^T): the variance gradient of
+// the Kuf path for kernels whose e factor differs from k
+hipError_t lower_dot(hipStream_t st, const double* Lu, const double* Q, int M, int Mp, double* out);
 hipError_t wcat_transpose(hipStream_t st, const double* Wcat, int Mp, int D, double* WT);
 hipError_t sub_identity(hipStream_t st, double* S, int M, int Mp, int batch);
 hipError_t symmetrize_lower(hipStream_t st, double* G, int Mp, int batch);
@@ -63,8 +89,8 @@ struct ZSource {           // where the N(0,1) draws of one layer come from
   long Ntot;               // row count of the injected array
 };
 
-hipError_t rbf_kuf(hipStream_t st, const double* Xin, long P, long x_row0, const double* Z, const double* var,
-                   const double* ls, int M, int Mp, int Din, double* Kt);
+hipError_t rbf_kuf(hipStream_t st, int kind, const double* Xin, long P, long x_row0, const double* Z, const double* var,
+                   const double* ls, int M, int Mp, int Din, double* Kt, double* Et /* e factors, or null */);
 // var/mean/sample stage of a layer (layers.py:249-278 + utils.py:41) from the GEMM epilogue partials.
 // `dedup`: the P rows are the Nc data points of the first layer (identical for every sample s); F is always
 // written for all S*Nc rows.

@@ -63,7 +63,8 @@ __device__ __forceinline__ void block_atomic_add(double v, double* dst, double* 
 }
 
 // ---------------------------------------------------------------------------------------- Kuf (point-major)
-// Kt[p][m] = var * exp(-0.5 |(x_p - z_m)/l|^2)   (reference: covs.Kuf, layers.py:243; gpflow SquaredExponential).
+// Kt[p][m] = k(x_p, z_m): var * exp(-0.5 |(x_p - z_m)/l|^2) for the squared exponential, Matern32/52 through
+// stationary_k (reference: covs.Kuf, layers.py:243; gpflow kernels).  Et (optional) = -2 dk/d(r2), kept for the backward.
 // One thread per inducing point m (its pre-scaled z row lives in registers), the block walks over points: the
 // point's x is the same for every lane (scalar loads), so the kernel issues no per-element vector loads at all —
 // the first version (16 loads per element) was load-issue bound at 3x this time.
@@ -71,7 +72,8 @@ template <int DIN>
 __global__ __launch_bounds__(256) void rbf_kuf_kernel(const double* __restrict__ Xin, long P, long x_row0,
                                                       const double* __restrict__ Z, const double* __restrict__ var,
                                                       const double* __restrict__ ls, int M, int Mp, int Din,
-                                                      double* __restrict__ Kt, int pts_per_block) {
+                                                      double* __restrict__ Kt, int pts_per_block, int kind,
+                                                      double* __restrict__ Et) {
   const int m = blockIdx.y * 256 + threadIdx.x;
   const int din = DIN > 0 ? DIN : Din;
   double zs[DIN > 0 ? DIN : 1], il[DIN > 0 ? DIN : 1];
@@ -94,24 +96,33 @@ __global__ __launch_bounds__(256) void rbf_kuf_kernel(const double* __restrict__
     } else {
       for (int j = 0; j < din; ++j) { const double d = (x[j] - ((m < M) ? Z[(long)m * din + j] : 0.0)) / ls[j]; r2 += d * d; }
     }
-    if (m < Mp) Kt[p * Mp + m] = (m < M) ? v0 * exp(-0.5 * r2) : 0.0;
+    if (m < Mp) {
+      if (kind == 0) {
+        Kt[p * Mp + m] = (m < M) ? v0 * exp(-0.5 * r2) : 0.0;
+      } else {
+        double k, e;
+        stationary_k(kind, v0, r2, k, e);
+        Kt[p * Mp + m] = (m < M) ? k : 0.0;
+        if (Et) Et[p * Mp + m] = (m < M) ? e : 0.0;
+      }
+    }
   }
 }
 
-hipError_t rbf_kuf(hipStream_t st, const double* Xin, long P, long x_row0, const double* Z, const double* var,
-                   const double* ls, int M, int Mp, int Din, double* Kt) {
+hipError_t rbf_kuf(hipStream_t st, int kind, const double* Xin, long P, long x_row0, const double* Z, const double* var,
+                   const double* ls, int M, int Mp, int Din, double* Kt, double* Et) {
   if (P == 0) return hipSuccess;
   int ppb = 64;
   while (ppb > 1 && (P + ppb - 1) / ppb < 2048) ppb >>= 1;           // enough blocks to fill the chip
   dim3 grid((unsigned)((P + ppb - 1) / ppb), (unsigned)((Mp + 255) / 256));
   switch (Din) {
-    case 1: hipLaunchKernelGGL(rbf_kuf_kernel<1>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb); break;
-    case 2: hipLaunchKernelGGL(rbf_kuf_kernel<2>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb); break;
-    case 3: hipLaunchKernelGGL(rbf_kuf_kernel<3>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb); break;
-    case 4: hipLaunchKernelGGL(rbf_kuf_kernel<4>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb); break;
-    case 8: hipLaunchKernelGGL(rbf_kuf_kernel<8>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb); break;
-    case 16: hipLaunchKernelGGL(rbf_kuf_kernel<16>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb); break;
-    default: hipLaunchKernelGGL(rbf_kuf_kernel<0>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb); break;
+    case 1: hipLaunchKernelGGL(rbf_kuf_kernel<1>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb, kind, Et); break;
+    case 2: hipLaunchKernelGGL(rbf_kuf_kernel<2>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb, kind, Et); break;
+    case 3: hipLaunchKernelGGL(rbf_kuf_kernel<3>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb, kind, Et); break;
+    case 4: hipLaunchKernelGGL(rbf_kuf_kernel<4>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb, kind, Et); break;
+    case 8: hipLaunchKernelGGL(rbf_kuf_kernel<8>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb, kind, Et); break;
+    case 16: hipLaunchKernelGGL(rbf_kuf_kernel<16>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb, kind, Et); break;
+    default: hipLaunchKernelGGL(rbf_kuf_kernel<0>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Din, Kt, ppb, kind, Et); break;
   }
   LAUNCH_CHECK();
 }

@@ -9,29 +9,33 @@ namespace dgp {
 #define LAUNCH_CHECK() return hipGetLastError()
 
 // ---------------------------------------------------------------------------------------- Kuu
-__global__ void rbf_kuu_kernel(const double* __restrict__ Z, const double* __restrict__ var,
-                               const double* __restrict__ ls, int M, int Mp, int Din, double* __restrict__ Kuu) {
+__global__ void rbf_kuu_kernel(int kind, const double* __restrict__ Z, const double* __restrict__ var,
+                               const double* __restrict__ ls, int M, int Mp, int Din, double* __restrict__ Kuu,
+                               double* __restrict__ Euu) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)Mp * Mp) return;
   const int m = (int)(idx / Mp), n = (int)(idx % Mp);
-  double v;
+  double v, e = 0.0;
   if (m < M && n < M) {
     double r2 = 0.0;
     for (int j = 0; j < Din; ++j) {
       const double d = (Z[(long)m * Din + j] - Z[(long)n * Din + j]) / ls[j];
       r2 += d * d;
     }
-    v = var[0] * exp(-0.5 * r2) + (m == n ? kJitter : 0.0);
+    stationary_k(kind, var[0], r2, v, e);
+    v += (m == n ? kJitter : 0.0);
   } else {
     v = (m == n) ? 1.0 : 0.0;
   }
   Kuu[idx] = v;
+  if (Euu) Euu[idx] = e;
 }
 
-hipError_t rbf_kuu(hipStream_t st, const double* Z, const double* var, const double* ls, int M, int Mp, int Din,
-                   double* Kuu) {
+hipError_t rbf_kuu(hipStream_t st, int kind, const double* Z, const double* var, const double* ls, int M, int Mp, int Din,
+                   double* Kuu, double* Euu) {
   const long n = (long)Mp * Mp;
-  hipLaunchKernelGGL(rbf_kuu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Z, var, ls, M, Mp, Din, Kuu);
+  hipLaunchKernelGGL(rbf_kuu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, kind, Z, var, ls, M, Mp, Din, Kuu,
+                     Euu);
   LAUNCH_CHECK();
 }
 
@@ -274,7 +278,8 @@ __global__ __launch_bounds__(256) void rbf_kuf_bwd_finish_kernel(const double* _
                                                                  const double* __restrict__ vsum, const double* __restrict__ Z,
                                                                  const double* __restrict__ var, const double* __restrict__ ls,
                                                                  int M, int Din, double* __restrict__ dZ,
-                                                                 double* __restrict__ dls, double* __restrict__ dvar) {
+                                                                 double* __restrict__ dls, double* __restrict__ dvar,
+                                                                 const double* __restrict__ kdot) {
   __shared__ double sh[16];
   const int j = blockIdx.x, w = Din + 1;
   const double l = ls[j];
@@ -293,12 +298,34 @@ __global__ __launch_bounds__(256) void rbf_kuf_bwd_finish_kernel(const double* _
     double lt = 0.0, vt = 0.0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { lt += sh[i]; vt += sh[8 + i]; }
     dls[j] = (lt + x2rs[j]) / (l * l * l);
-    if (j == 0) dvar[0] = vt / var[0] + vsum[0];
+    if (j == 0) dvar[0] = (kdot ? kdot[0] : vt) / var[0] + vsum[0];
   }
 }
 hipError_t rbf_kuf_bwd_finish(hipStream_t st, const double* GX, const double* x2rs, const double* vsum, const double* Z,
-                              const double* var, const double* ls, int M, int Din, double* dZ, double* dls, double* dvar) {
-  hipLaunchKernelGGL(rbf_kuf_bwd_finish_kernel, dim3(Din), dim3(256), 0, st, GX, x2rs, vsum, Z, var, ls, M, Din, dZ, dls, dvar);
+                              const double* var, const double* ls, int M, int Din, double* dZ, double* dls, double* dvar,
+                              const double* kdot) {
+  hipLaunchKernelGGL(rbf_kuf_bwd_finish_kernel, dim3(Din), dim3(256), 0, st, GX, x2rs, vsum, Z, var, ls, M, Din, dZ, dls, dvar,
+                     kdot);
+  LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void lower_dot_kernel(const double* __restrict__ Lu, const double* __restrict__ Q, int M,
+                                                        int Mp, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double a = 0.0;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)M * M; idx += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / M), j = (int)(idx % M);
+    if (j <= i) a += Lu[(long)i * Mp + j] * Q[(long)i * Mp + j];
+  }
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+hipError_t lower_dot(hipStream_t st, const double* Lu, const double* Q, int M, int Mp, double* out) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lower_dot_kernel, dim3(16), dim3(256), 0, st, Lu, Q, M, Mp, out);
   LAUNCH_CHECK();
 }
 
@@ -465,6 +492,7 @@ hipError_t phi_tril_halfdiag(hipStream_t st, double* T, int Mp, int batch) {
 
 // RBF backward through Kuu = K(Z,Z) + jitter*I with dKuu = sym(S)   
 __global__ __launch_bounds__(64) void rbf_kuu_bwd_kernel(const double* __restrict__ S, const double* __restrict__ Kuu,
+                                                         const double* __restrict__ Euu,
                                                          const double* __restrict__ Z, const double* __restrict__ var,
                                                          const double* __restrict__ ls, int M, int Mp, int Din,
                                                          double* __restrict__ dZ, double* __restrict__ dls,
@@ -475,11 +503,12 @@ __global__ __launch_bounds__(64) void rbf_kuu_bwd_kernel(const double* __restric
   double zacc = 0.0, lacc = 0.0, vacc = 0.0;
   for (int n = lane; n < M; n += 64) {
     const double k0 = Kuu[(long)m * Mp + n] - (m == n ? kJitter : 0.0);
-    const double h = 0.5 * (S[(long)m * Mp + n] + S[(long)n * Mp + m]) * k0;
+    const double sym = 0.5 * (S[(long)m * Mp + n] + S[(long)n * Mp + m]);
+    const double h = sym * (Euu ? Euu[(long)m * Mp + n] : k0);       // dKuu .* e: inputs and lengthscales
     const double dl = zm - Z[(long)n * Din + j];
     zacc += h * dl;
     lacc += h * dl * dl;
-    vacc += h;
+    vacc += sym * k0;                                                 // dKuu .* k: variance
   }
   for (int o = 32; o > 0; o >>= 1) {
     zacc += __shfl_down(zacc, o);
@@ -492,9 +521,9 @@ __global__ __launch_bounds__(64) void rbf_kuu_bwd_kernel(const double* __restric
     if (j == 0) unsafeAtomicAdd(dvar, vacc / var[0]);
   }
 }
-hipError_t rbf_kuu_bwd(hipStream_t st, const double* S, const double* Kuu, const double* Z, const double* var,
-                       const double* ls, int M, int Mp, int Din, double* dZ, double* dls, double* dvar) {
-  hipLaunchKernelGGL(rbf_kuu_bwd_kernel, dim3(M, Din), dim3(64), 0, st, S, Kuu, Z, var, ls, M, Mp, Din, dZ, dls, dvar);
+hipError_t rbf_kuu_bwd(hipStream_t st, const double* S, const double* Kuu, const double* Euu, const double* Z,
+                       const double* var, const double* ls, int M, int Mp, int Din, double* dZ, double* dls, double* dvar) {
+  hipLaunchKernelGGL(rbf_kuu_bwd_kernel, dim3(M, Din), dim3(64), 0, st, S, Kuu, Euu, Z, var, ls, M, Mp, Din, dZ, dls, dvar);
   LAUNCH_CHECK();
 }
 

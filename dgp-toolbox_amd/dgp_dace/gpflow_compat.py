@@ -108,6 +108,39 @@ class SquaredExponential:
 RBF = SquaredExponential
 
 
+class Matern32(SquaredExponential):
+    """gpflow.kernels.Matern32: variance (1 + sqrt3 r) exp(-sqrt3 r), r = sqrt(max(|x/l - x'/l|^2, 1e-36))."""
+
+    kind = "matern32"
+
+
+class Matern52(SquaredExponential):
+    """gpflow.kernels.Matern52: variance (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r)."""
+
+    kind = "matern52"
+
+
+KERNEL_KINDS = {"rbf": 0, "matern32": 1, "matern52": 2}          # dgp_kernel_kind of include/dgp_abi.h
+_KERNEL_CLASSES = {"SquaredExponential": SquaredExponential, "RBF": SquaredExponential, "Matern32": Matern32,
+                   "Matern52": Matern52}
+
+
+def kernel_matrix_host(kern, Z):
+    """K(Z, Z) in NumPy for the constructor-time prior initialisation (layers.py:220-223 does this on the host too)."""
+    Zs = Z / kern.lengthscales._value
+    sq = np.sum(Zs * Zs, -1)
+    r2 = -2.0 * Zs @ Zs.T + sq[:, None] + sq[None, :]
+    v = kern.variance._value
+    if kern.kind == "rbf":
+        return v * np.exp(-0.5 * r2)
+    r = np.sqrt(np.maximum(r2, 1e-36))
+    if kern.kind == "matern32":
+        a = np.sqrt(3.0) * r
+        return v * (1.0 + a) * np.exp(-a)
+    a = np.sqrt(5.0) * r
+    return v * (1.0 + a + 5.0 / 3.0 * r * r) * np.exp(-a)
+
+
 class Gaussian:
     """gpflow.likelihoods.Gaussian: variance with the Softplus + Shift(1e-6) transform."""
 
@@ -149,20 +182,21 @@ class mean_functions:
 
 
 def kernel_from_any(k, input_dim):
-    """Accept our stand-in or a real gpflow kernel; only the squared exponential is on this path."""
+    """Accept our stand-ins or real gpflow kernels (read by attribute): SquaredExponential/RBF, Matern32, Matern52
+    with scalar or ARD lengthscales -- the kernels SO_BO.py:192-197,239-244 constructs."""
     if isinstance(k, SquaredExponential):
         if k.lengthscales.shape == (1,) and input_dim > 1:       # isotropic -> ARD storage
             k.lengthscales = Parameter(np.full(input_dim, k.lengthscales._value[0]), "lengthscales", "softplus")
         return k
     name = type(k).__name__
-    if name not in ("SquaredExponential", "RBF"):
+    if name not in _KERNEL_CLASSES:
         raise NotImplementedError(
-            f"kernel {name}: only the squared-exponential (RBF) kernel is implemented on the HIP path "
-            "(Matern32/52 of SO_BO.py:194-197 are listed as a next row in DESIGN.md)")
+            f"kernel {name}: the HIP path implements the stationary kernels the reference's DGP callers use "
+            "(SquaredExponential/RBF, Matern32, Matern52); composite kernels belong to MF-DGP (DESIGN.md §9)")
     ls = np.atleast_1d(_val(k.lengthscales))
     if ls.size == 1 and input_dim > 1:
         ls = np.full(input_dim, ls[0])
-    return SquaredExponential(variance=_val(k.variance), lengthscales=ls)
+    return _KERNEL_CLASSES[name](variance=_val(k.variance), lengthscales=ls)
 
 
 def likelihood_from_any(lik):

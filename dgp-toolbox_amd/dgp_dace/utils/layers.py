@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from ..gpflow_compat import Parameter, as_tensor
+from ..gpflow_compat import KERNEL_KINDS, Parameter, as_tensor, kernel_matrix_host
 
 JITTER = 1e-6      # gpflow.default_jitter() (layers.py:222)
 MEAN_KINDS = {"zero": 0, "identity": 1, "linear": 2}
@@ -22,14 +22,6 @@ class InducingPoints:
 
     def __init__(self, Z):
         self.Z = Parameter(np.array(Z, dtype=np.float64), "Z")
-
-
-def _rbf_K_host(kern, Z):
-    """K(Z, Z) for the constructor-time prior initialisation only (layers.py:220-223 does this in NumPy too)."""
-    Zs = Z / kern.lengthscales._value
-    sq = np.sum(Zs * Zs, -1)
-    r2 = -2.0 * Zs @ Zs.T + sq[:, None] + sq[None, :]
-    return kern.variance._value * np.exp(-0.5 * r2)
 
 
 class Layer:
@@ -57,7 +49,7 @@ class SVGP_Layer(Layer):
         if self.white:
             q_sqrt = np.tile(np.eye(M)[None], [self.num_outputs, 1, 1])
         else:   # q(u) = prior p(u): q_sqrt = chol(K(Z) + jitter I), once, on the host as the reference does
-            Lu = np.linalg.cholesky(_rbf_K_host(kern, Z) + np.eye(M) * JITTER)
+            Lu = np.linalg.cholesky(kernel_matrix_host(kern, Z) + np.eye(M) * JITTER)
             q_sqrt = np.tile(Lu[None], [self.num_outputs, 1, 1])
         self.q_sqrt = Parameter(q_sqrt, "q_sqrt", "tril")
         self._private = None
@@ -68,8 +60,8 @@ class SVGP_Layer(Layer):
         return self.feature.Z.shape[1]
 
     def desc(self):
-        return (self.input_dim, self.num_outputs, self.num_inducing, 1 if self.white else 0, 0,
-                MEAN_KINDS[self.mean_function.kind])
+        return (self.input_dim, self.num_outputs, self.num_inducing, 1 if self.white else 0,
+                KERNEL_KINDS[self.kern.kind], MEAN_KINDS[self.mean_function.kind])
 
     def parameters(self):
         """[Z, variance, lengthscales, q_mu, q_sqrt] — the packing order of dgp_model_set."""

@@ -32,7 +32,11 @@ enum dgp_status {
   DGP_ERR_NONFINITE = -5  /* NaN/Inf in the ELBO (TF would propagate NaN silently)          */
 };
 
-enum dgp_kernel_kind { DGP_KERNEL_RBF = 0 };                 /* gpflow.kernels.SquaredExponential (ARD) */
+enum dgp_kernel_kind {      /* gpflow stationary kernels with ARD lengthscales (SO_BO.py:192-197,239-244) */
+  DGP_KERNEL_RBF = 0,       /* SquaredExponential / RBF */
+  DGP_KERNEL_MATERN32 = 1,
+  DGP_KERNEL_MATERN52 = 2
+};
 enum dgp_mean_kind { DGP_MEAN_ZERO = 0, DGP_MEAN_IDENTITY = 1, DGP_MEAN_LINEAR = 2 };
 
 /* One SVGP_Layer (layers.py:181-224): kernel on D_in inputs, M inducing points, D_out outputs. */

@@ -39,6 +39,8 @@ LIK_VAR_LOWER = 1e-6   # gpflow.likelihoods.Gaussian DEFAULT_VARIANCE_LOWER_BOUN
 class RBF:
     """gpflow.kernels.SquaredExponential (ARD).  K = s2 * exp(-0.5 r2), r2 by the expanded form."""
 
+    kind = "rbf"
+
     def __init__(self, variance=1.0, lengthscales=1.0):
         self.variance = float(variance)
         self.lengthscales = np.atleast_1d(np.asarray(lengthscales, dtype=np.float64)).copy()
@@ -46,22 +48,46 @@ class RBF:
     def _scaled(self, X):
         return X / self.lengthscales
 
-    def K(self, X, X2=None):
+    def _r2(self, X, X2=None):
+        """gpflow.utilities.ops.square_distance of the scaled inputs (expanded form, no clamp)  [ext]"""
         Xs = self._scaled(X)
         if X2 is None:
             sq = np.sum(Xs * Xs, -1)
-            r2 = -2.0 * Xs @ Xs.T + sq[:, None] + sq[None, :]
-        else:
-            X2s = self._scaled(X2)
-            r2 = (-2.0 * Xs @ X2s.T + np.sum(Xs * Xs, -1)[:, None]
-                  + np.sum(X2s * X2s, -1)[None, :])
-        return self.variance * np.exp(-0.5 * r2)
+            return -2.0 * Xs @ Xs.T + sq[:, None] + sq[None, :]
+        X2s = self._scaled(X2)
+        return -2.0 * Xs @ X2s.T + np.sum(Xs * Xs, -1)[:, None] + np.sum(X2s * X2s, -1)[None, :]
+
+    def K(self, X, X2=None):
+        return self.variance * np.exp(-0.5 * self._r2(X, X2))
 
     def K_diag(self, X):
         return np.full(X.shape[0], self.variance)
 
     def copy(self):
-        return RBF(self.variance, self.lengthscales.copy())
+        return type(self)(self.variance, self.lengthscales.copy())
+
+
+class Matern32(RBF):
+    """gpflow.kernels.Matern32 (SO_BO.py:194-195,241-242): s2 (1 + sqrt3 r) exp(-sqrt3 r), r = sqrt(max(r2, 1e-36))
+    (gpflow IsotropicStationary.scaled_squared_euclid_dist / K_r; the clamp keeps the sqrt differentiable)  [ext]"""
+
+    kind = "matern32"
+
+    def K(self, X, X2=None):
+        r = np.sqrt(np.maximum(self._r2(X, X2), 1e-36))
+        a = np.sqrt(3.0) * r
+        return self.variance * (1.0 + a) * np.exp(-a)
+
+
+class Matern52(RBF):
+    """gpflow.kernels.Matern52 (SO_BO.py:196-197,243-244): s2 (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r)  [ext]"""
+
+    kind = "matern52"
+
+    def K(self, X, X2=None):
+        r = np.sqrt(np.maximum(self._r2(X, X2), 1e-36))
+        a = np.sqrt(5.0) * r
+        return self.variance * (1.0 + a + 5.0 / 3.0 * r * r) * np.exp(-a)
 
 
 class MeanFunction:

@@ -34,7 +34,8 @@ def params_from_model(model):
     return P
 
 
-def rbf_K(variance, lengthscales, X, X2=None):
+def rbf_K(variance, lengthscales, X, X2=None, kind="rbf"):
+    """Stationary kernels of dgp_oracle.py (RBF / Matern32 / Matern52) on torch tensors."""
     Xs = X / lengthscales
     if X2 is None:
         sq = (Xs * Xs).sum(-1)
@@ -42,7 +43,16 @@ def rbf_K(variance, lengthscales, X, X2=None):
     else:
         X2s = X2 / lengthscales
         r2 = -2.0 * Xs @ X2s.T + (Xs * Xs).sum(-1)[:, None] + (X2s * X2s).sum(-1)[None, :]
-    return variance * torch.exp(-0.5 * r2)
+    if kind == "rbf":
+        return variance * torch.exp(-0.5 * r2)
+    r = torch.sqrt(torch.clamp(r2, min=1e-36))
+    if kind == "matern32":
+        a = math.sqrt(3.0) * r
+        return variance * (1.0 + a) * torch.exp(-a)
+    if kind == "matern52":
+        a = math.sqrt(5.0) * r
+        return variance * (1.0 + a + 5.0 / 3.0 * r * r) * torch.exp(-a)
+    raise ValueError(kind)
 
 
 def mean_fn(layer, X):
@@ -57,9 +67,9 @@ def mean_fn(layer, X):
 def conditional_ND(layer, p, X):
     """layers.py:237-278, dense form."""
     M, D = p["q_mu"].shape
-    Ku = rbf_K(p["variance"], p["lengthscales"], p["Z"]) + JITTER * torch.eye(M, dtype=DT)
+    Ku = rbf_K(p["variance"], p["lengthscales"], p["Z"], kind=layer.kern.kind) + JITTER * torch.eye(M, dtype=DT)
     Lu = torch.linalg.cholesky(Ku)
-    Kuf = rbf_K(p["variance"], p["lengthscales"], p["Z"], X)
+    Kuf = rbf_K(p["variance"], p["lengthscales"], p["Z"], X, kind=layer.kern.kind)
     A = torch.linalg.solve_triangular(Lu, Kuf, upper=False)
     if not layer.white:
         A = torch.linalg.solve_triangular(Lu.T, A, upper=True)
@@ -78,7 +88,7 @@ def layer_KL(layer, p):
     q_sqrt = torch.tril(p["q_sqrt"])
     KL = -0.5 * D * M - 0.5 * torch.log(torch.diagonal(q_sqrt, dim1=1, dim2=2) ** 2).sum()
     if not layer.white:
-        Ku = rbf_K(p["variance"], p["lengthscales"], p["Z"]) + JITTER * torch.eye(M, dtype=DT)
+        Ku = rbf_K(p["variance"], p["lengthscales"], p["Z"], kind=layer.kern.kind) + JITTER * torch.eye(M, dtype=DT)
         Lu = torch.linalg.cholesky(Ku)
         KL = KL + torch.log(torch.diagonal(Lu)).sum() * D
         LiS = torch.linalg.solve_triangular(Lu[None].expand(D, -1, -1), q_sqrt, upper=False)

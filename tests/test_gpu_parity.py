@@ -502,3 +502,85 @@ def test_stored_t_formulation_gives_the_same_gradient(monkeypatch):
         ctx.grad_finish()
         grads.append(ctx.grad_get())
     _close(grads[1], grads[0], rtol=0, atol=1e-10 * np.abs(grads[0]).max())
+
+
+def _matern_pair(white, seed=21, N=70, D=3, M=20, units=(4, 2)):
+    """Product and oracle models with Matern32 / Matern52 / RBF layers in a non-trivial state."""
+    from dgp_dace.gpflow_compat import RBF, Gaussian, Matern32, Matern52
+    from dgp_dace.models.dgp import DGP
+    rng = np.random.default_rng(seed)
+    X, Y, Z = rng.uniform(-1, 1, (N, D)), rng.standard_normal((N, 1)), rng.uniform(-1, 1, (M, D))
+    dims = [D] + list(units)
+    pk = [Matern32, Matern52, RBF]
+    ok = [O.Matern32, O.Matern52, O.RBF]
+    var = [1.3, 0.8, 1.1]
+    ls = [rng.uniform(0.6, 1.5, d) for d in dims]
+    m = DGP(X, Y, Z, [pk[i](var[i], ls[i]) for i in range(3)], list(units), Gaussian(), white=white, num_samples=4)
+    om = O.OracleDGP(X, Y, Z, [ok[i](var[i], ls[i]) for i in range(3)], list(units), lik_variance=1.0, white=white,
+                     num_samples=4)
+    for l, lo in zip(m.layers, om.layers):
+        np.testing.assert_allclose(l.q_sqrt.numpy(), lo.q_sqrt, rtol=1e-11, atol=1e-13)     # host init uses the kernel
+        q = rng.standard_normal(lo.q_mu.shape) * 0.3
+        qs = lo.q_sqrt * (0.5 + 0.1 * rng.random((lo.q_sqrt.shape[0], 1, 1)))
+        l.q_mu.assign(q); lo.q_mu = q.copy()
+        l.q_sqrt.assign(qs); lo.q_sqrt = qs.copy()
+    return m, om, (X, Y)
+
+
+@pytest.mark.parametrize("white", [False, True])
+def test_matern_kernels_forward_gradient_and_vjp(white):
+    """Matern32 / Matern52 layers (SO_BO.py:194-197,241-244) on the HIP path: propagate, ELBO, the full parameter
+    gradient and the input VJP against the oracle (NumPy forward, torch autograd backward)."""
+    import dgp_oracle_torch as OT
+    m, om, (X, Y) = _matern_pair(white)
+    S, N = 4, X.shape[0]
+    rng = np.random.default_rng(1)
+    zs = [rng.standard_normal((S, N, l.num_outputs)) for l in om.layers]
+    Fs, Fm, Fv = m.propagate(X, S=S, zs=zs)
+    oFs, oFm, oFv = om.propagate(X, S, zs)
+    for i in range(3):                 # the oracle forms r2 by the expanded product, the device by differences:
+        _close(Fm[i], oFm[i], rtol=1e-8, atol=1e-9)       # 1e-16 in r2, amplified by cond(Kuu + 1e-6 I)
+        _close(Fv[i], oFv[i], rtol=1e-8, atol=1e-9)
+        _close(Fs[i], oFs[i], rtol=1e-8, atol=1e-9)
+    ctx = m._sync_model()
+    m._sync_data(m.data)
+    want_elbo, G = OT.elbo_and_grads(om, zs, S)
+    ctx.grad_partial(S, 0, zs)
+    elbo = ctx.grad_finish(want_elbo=True)
+    assert abs(elbo - want_elbo) < 1e-9 * abs(want_elbo)
+    got = split_flat(m, ctx.grad_get())
+    for i in range(3):
+        for nm in ("Z", "variance", "lengthscales", "q_mu", "q_sqrt"):
+            w = np.asarray(G["layers"][i][nm])
+            _close(got[(i, nm)], w.reshape(got[(i, nm)].shape), rtol=0, atol=2e-8 * max(1e-3, np.abs(w).max()))
+    # input VJP through the Matern layers
+    Xn = X[:9]
+    zn = [z[:, :9] for z in zs]
+    fb, mb, vb = (rng.standard_normal((S, 9, 1)) for _ in range(3))
+    want, *_ = OT.propagate_vjp(om, Xn, zn, S, fb, mb, vb)
+    _close(m.propagate_vjp(Xn, S=S, f_bar=fb, mean_bar=mb, var_bar=vb, zs=zn), want, rtol=0, atol=1e-8 * np.abs(want).max())
+
+
+def test_matern_two_adam_iterations_follow_the_oracle():
+    """Two loop bodies of optimize_adam on Matern layers, device Philox stream included (evaluation e: seed 17 + e)."""
+    import dgp_oracle_train as OTr
+    m, om, _ = _matern_pair(False, seed=33)
+    m.seed = 17
+    tr = OTr.OracleTrainer(om, base_seed=17)
+    adam = tr.new_adam(0.01, 0.9, 0.999)
+    want = [tr.adam_iteration(adam) for _ in range(2)]
+    ctx = m._sync_model()
+    ctx.adam_reset()
+    got = []
+    for _ in range(2):
+        c = m._grad_step(m.data)
+        c.adam_step(0.01, 0.9, 0.999, 1e-7, m._trainable_flags())
+        m._device_newer = True
+        got.append(c.last_elbo())
+    _close(got, want, rtol=1e-7)
+    for l, lo in zip(m.layers, om.layers):
+        _close(l.kern.lengthscales.numpy(), lo.kern.lengthscales, rtol=1e-8)
+        _close(l.kern.variance.numpy(), lo.kern.variance, rtol=1e-8)
+        _close(l.feature.Z.numpy(), lo.Z, rtol=1e-8, atol=1e-9)
+        _close(l.q_mu.numpy(), lo.q_mu, rtol=1e-8, atol=1e-9)
+        _close(l.q_sqrt.numpy(), lo.q_sqrt, rtol=1e-8, atol=1e-9)

@@ -84,11 +84,17 @@ def test_only_the_accelerated_subset_is_accepted():
     from dgp_dace.gpflow_compat import RBF, Gaussian, kernel_from_any
     from dgp_dace.models.dgp import DGP
 
-    class Matern32:
-        variance, lengthscales = 1.0, np.ones(1)
+    class Matern32:                      # a foreign (gpflow-like) object is read by attribute
+        variance, lengthscales = 2.0, np.ones(1) * 0.5
+
+    k = kernel_from_any(Matern32(), 3)
+    assert k.kind == "matern32" and k.lengthscales.shape == (3,) and float(k.variance.numpy()) == 2.0
+
+    class Sum:                           # composite kernels (MF-DGP) are not on this path
+        kernels = []
 
     with pytest.raises(NotImplementedError):
-        kernel_from_any(Matern32(), 1)
+        kernel_from_any(Sum(), 1)
     X, Y, Z = notebook_data()
     with pytest.raises(Exception):
         DGP(X, Y, Z, [RBF(1.0, [1.0])] * 2, [1, 1], Gaussian())          # one kernel per layer is required

@@ -122,3 +122,28 @@ def test_layer_init_mean_functions():
     np.testing.assert_array_equal(m.layers[1].mean_function.A, np.eye(2, 4))
     np.testing.assert_allclose(m.layers[1].Z, Z @ V[:2].T)
     np.testing.assert_allclose(m.layers[2].Z, Z @ V[:2].T @ np.eye(2, 4))
+
+
+def test_matern_kernels_against_scikit_learn():
+    """Independent pin of the restated gpflow Matern32/52 (the reference holds no fixture for them): scikit-learn's
+    Matern(nu=1.5 / 2.5) with anisotropic length scales."""
+    from sklearn.gaussian_process.kernels import Matern
+    rng = np.random.default_rng(0)
+    X, X2, ls = rng.standard_normal((9, 3)), rng.standard_normal((5, 3)), np.array([0.7, 1.3, 2.1])
+    for cls, nu in ((O.Matern32, 1.5), (O.Matern52, 2.5)):
+        k = cls(1.7, ls)
+        np.testing.assert_allclose(k.K(X, X2), 1.7 * Matern(length_scale=ls, nu=nu)(X, X2), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(k.K(X), 1.7 * Matern(length_scale=ls, nu=nu)(X), rtol=1e-12, atol=1e-7)
+        np.testing.assert_allclose(k.K_diag(X), np.full(9, 1.7))
+        assert type(k.copy()) is cls
+
+
+def test_matern_torch_twin_matches_numpy_oracle():
+    import torch
+    import dgp_oracle_torch as OT
+    rng = np.random.default_rng(1)
+    X, Z, ls = rng.standard_normal((6, 2)), rng.standard_normal((4, 2)), np.array([0.9, 1.4])
+    for cls in (O.RBF, O.Matern32, O.Matern52):
+        k = cls(1.2, ls)
+        got = OT.rbf_K(torch.tensor(1.2, dtype=OT.DT), torch.tensor(ls), torch.tensor(Z), torch.tensor(X), kind=k.kind)
+        np.testing.assert_allclose(got.numpy(), k.K(Z, X), rtol=1e-13)
