@@ -65,6 +65,17 @@ def alg_flops_step(N, S, dims, M, Dy):
     return total
 
 
+def survey_flops_step(N, S, dims, M, Dy, white=False):
+    """SURVEY.md §8d's own count, for context: F_step = 3 * sum_layers P*[M(2 D_in + 3) + w M^2 + 2 M D_out +
+    D_out M (M+3) + 6 D_out] with P = S*N in EVERY layer and w = 2 solves (non-white).  It credits work this
+    implementation does not execute (the first layer once per sample, the second triangular solve)."""
+    w = 1.0 if white else 2.0
+    douts = dims[1:] + [Dy]
+    P = float(N) * S
+    return 3.0 * sum(P * (M * (2 * din + 3) + w * M * M + 2 * M * dout + dout * M * (M + 3.0) + 6 * dout)
+                     for din, dout in zip(dims, douts))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,8 +131,10 @@ def main():
     def fence():
         ctx.sync()
         if dist:
+            torch.cuda.synchronize()
             dist.barrier()
             ctx.sync()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -168,7 +181,9 @@ def main():
                          "kernel_ms_per_step": mf["ms"] / args.steps, "launches_per_step": mf["launches"] / args.steps,
                          "alg_flops_per_step_rank0": mf["alg_flops"] / args.steps,
                          "whole_step_frac": alg_flops_step(args.N, args.S, dims, args.M, 1) / world / (dt / args.steps)
-                                            / 1e12 / FP64_MFMA_PEAK_TFLOPS},
+                                            / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                         "whole_step_frac_by_survey_8d_count": survey_flops_step(args.N, args.S, dims, args.M, 1) / world
+                                                               / (dt / args.steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
             "breakdown_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
             "elbo_last": elbo_last, "device": name,
         }
