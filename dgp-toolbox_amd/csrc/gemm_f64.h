@@ -544,6 +544,12 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   }
 
   // ---- epilogue: acc[i][j][e] of lane l is C[rowblk*16 + 4*((l&15)>>2) + (l>>4)][colblk*16 + 4e + (l&3)]
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] *= g.alpha;
   if (g.epi != 0) {
     // per-row sums of squares over this wave's columns: a lane holds 4 values of its row per fragment, the
     // 4 lanes l&3 = 0..3 of a quad hold the rest of that row's 16 columns
@@ -554,13 +560,38 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < FN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const double v = g.alpha * acc[i][j][r]; q += v * v; }
+        for (int r = 0; r < 4; ++r) q += acc[i][j][r] * acc[i][j][r];
       q += __shfl_xor(q, 1);
       q += __shfl_xor(q, 2);
       const long row = m0 + (long)(i * WR + wr) * 16 + 4 * (li >> 2) + lk;
       if ((li & 3) == 0 && row < g.M) rs[row] = q;
     }
     if (g.epi == 1) continue;
+  }
+  if (g.rank > 0) {
+    // rank-R update: a lane owns FM rows and 4*FN columns, so per q it needs FM + 4*FN factor values for its
+    // FM*FN*4 outputs (fetching both factors per output element cost 2 ms per dC launch at config 2)
+    for (int q = 0; q < g.rank; ++q) {
+      double rfq[FM], cfq[FN][4];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const long row = m0 + (long)(i * WR + wr) * 16 + 4 * (li >> 2) + lk;
+        rfq[i] = row < g.M ? g.rowf[row * g.rank + q] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long col = n0 + (long)(j * WC + wc) * 16 + 4 * r + (li & 3);
+          cfq[j][r] = col < g.N ? g.colf[col * g.rank + q] : 0.0;
+        }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] += rfq[i] * cfq[j][r];
+    }
   }
   const bool atomic = g.splits > 1;
 #pragma unroll
@@ -580,12 +611,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
         const long col = n0 + (long)(j * WC + wc) * 16 + 4 * r + (li & 3);
         if (row < g.M && col < g.N) {
           double* p = C + row * g.ldc + col;
-          double v = g.alpha * acc[i][j][r];
-          if (g.rank > 0) {
-            const double* rf = g.rowf + row * g.rank;
-            const double* cf = g.colf + col * g.rank;
-            for (int q = 0; q < g.rank; ++q) v += rf[q] * cf[q];
-          }
+          double v = acc[i][j][r];
           if (g.eadd != nullptr) v -= esc * g.eadd[row * g.ldc + col];
           if (atomic) unsafeAtomicAdd(p, v);
           else if (g.beta) *p += v;
