@@ -227,3 +227,22 @@ def test_infill_host_math_without_a_device():
     class Gpr: name = 'gpr'
     with pytest.raises(NotImplementedError):
         IC.EI(0.0, 2).run(Gpr(), np.zeros((1, 2)))
+
+
+def test_bench_flop_accounting_matches_the_survey_tables():
+    """bench.py's roofline numerators: SURVEY §8d's own count reproduces its table (config 2: 4.631e12, 2-alt:
+    2.620e12); the executed-formulation count credits the first layer once and one triangular solve."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert abs(bench.survey_flops_step(100_000, 10, [8, 8, 8], 256, 1) / 4.631e12 - 1) < 1e-3
+    assert abs(bench.survey_flops_step(100_000, 10, [8, 8], 256, 1) / 2.620e12 - 1) < 1e-3
+    assert abs(bench.survey_flops_step(1_000_000, 10, [16, 16, 16, 16], 512, 1) / 4.542e14 - 1) < 1e-3
+    ours = bench.alg_flops_step(100_000, 10, [8, 8, 8], 256, 1)
+    want = 3.0 * 256 * 257 * (100_000 * 9 + 1_000_000 * 9 + 1_000_000 * 2)
+    assert abs(ours / want - 1) < 1e-12 and ours < bench.survey_flops_step(100_000, 10, [8, 8, 8], 256, 1)
+    X, Y, Z = bench.synthetic(1000, 3, 16)
+    assert X.shape == (1000, 3) and Y.shape == (1000, 1) and Z.shape == (16, 3)
+    np.testing.assert_allclose(X.mean(0), 0, atol=1e-12)
+    np.testing.assert_allclose(Y.std(0), 1, rtol=1e-12)
