@@ -17,8 +17,9 @@
 // 21 % of it bank conflicts: rocprofv3 SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT).  Measured conflict-free pitches:
 //   k-contiguous image (A not transposed, B transposed): BK+4 doubles, a lane reads its two k values as one b128
 //     (pitch BK+2 is 2-way conflicted for both b64 and b128);
-//   n-contiguous B image: BN+8 doubles with the columns of every 16-column block stored grouped by (c mod 4),
-//     so that the four columns a lane feeds to the four MFMAs of a block are 32 contiguous bytes;
+//   n-contiguous B image: BN+8 doubles, natural column order: lane c feeds column 4 (c mod 4) + e of its 16-column
+//     block to the e-th of the four MFMAs, i.e. 32 contiguous bytes (the MFMA then yields, per lane, four
+//     CONSECUTIVE output columns, which the epilogue stores as one 32-byte piece);
 //   m-contiguous A image (A transposed): BM+8 doubles, b64 reads of consecutive rows.
 //   (In both, the lane groups lk and lk+1 of a 32-lane half read image rows two apart: a pitch of 8 mod 16
 //   doubles puts them on opposite halves of the 64 banks; BN+16 / BM+16 were 2-way conflicted.)
@@ -132,20 +133,14 @@ __device__ __forceinline__ void tile_load(double (&reg)[PASS][V], const double* 
   }
 }
 
-// position of column c inside the n-contiguous B image: columns of a 16-column block are grouped by (c mod 4)
-__device__ __forceinline__ int bpos(int c) { return (c & ~15) | ((c & 3) << 2) | ((c >> 2) & 3); }
-
-template <int ROWS, int COLS, int V, int TPR, int RPP, int PASS, int LDS_LD, bool PERM = false>
+template <int ROWS, int COLS, int V, int TPR, int RPP, int PASS, int LDS_LD>
 __device__ __forceinline__ void tile_store(const double (&reg)[PASS][V], double* __restrict__ s, int tid) {
   const int tr = tid / TPR, tc = (tid % TPR) * V;
 #pragma unroll
   for (int p = 0; p < PASS; ++p) {
     const int r = p * RPP + tr;
     if (r < ROWS) {
-      if constexpr (PERM) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) s[r * LDS_LD + bpos(tc + v)] = reg[p][v];
-      } else if constexpr (V == 2) {
+      if constexpr (V == 2) {
         d2_t v = {reg[p][0], reg[p][1]};
         *reinterpret_cast<d2_t*>(s + r * LDS_LD + tc) = v;
       } else {
@@ -298,14 +293,15 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     double* as = smem + buf * (Cfg::AS_SZ + Cfg::BS_SZ);
     double* bs = as + Cfg::AS_SZ;
     tile_store<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS, Cfg::LDA_S>(ra, as, tid);
-    tile_store<Cfg::B_ROWS, Cfg::B_COLS, VB, Cfg::B_TPR, Cfg::B_RPP, Cfg::B_PASS, Cfg::LDB_S, !TB>(rb, bs, tid);
+    tile_store<Cfg::B_ROWS, Cfg::B_COLS, VB, Cfg::B_TPR, Cfg::B_RPP, Cfg::B_PASS, Cfg::LDB_S>(rb, bs, tid);
   };
 
   // One k-step feeds 8 k values to 2 x 32 MFMAs: lane (li, lk) supplies k = 8 s + 2 lk + q in half-step q (any
   // assignment of k to the instruction's four k slots is legal as long as A and B agree), so that its two values
   // are adjacent in a k-contiguous image.  v_mfma_f64_4x4x4_4b multiplies, for each of its four blocks b, rows
-  // 4b..4b+3 of the A fragment with the columns supplied by lanes 4b..4b+3: lane c supplies column 4e + (c & 3) of
-  // the 16-column block for the e-th MFMA, so MFMA e yields the 16 x 4 strip of columns 4e..4e+3.
+  // 4b..4b+3 of the A fragment with the columns supplied by lanes 4b..4b+3: lane c supplies column 4 (c & 3) + e of
+  // the 16-column block to the e-th MFMA, so MFMA e yields columns {e, 4+e, 8+e, 12+e} and a lane ends up with the
+  // four consecutive columns 4 (c & 3) .. 4 (c & 3) + 3 of its row.
   //
   // Pipeline: the unit of work is a half-step (32 MFMAs).  The LDS reads of unit u+1 are issued under the MFMAs
   // of unit u (B fragments per half-step, A fragments per step because one b128 read brings both halves), also
@@ -349,7 +345,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 #else
       if constexpr (TB) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xb[j][e] = bs[(cb + 4 * e + (li & 3)) * Cfg::LDB_S + kk];
+        for (int e = 0; e < 4; ++e) xb[j][e] = bs[(cb + 4 * (li & 3) + e) * Cfg::LDB_S + kk];
       } else {
         const double* pq = bs + kk * Cfg::LDB_S + cb + (li & 3) * 4;
         const d2_t v0 = *reinterpret_cast<const d2_t*>(pq), v1 = *reinterpret_cast<const d2_t*>(pq + 2);
@@ -369,7 +365,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   };
   constexpr int N_MFMA = FM * FN * 4;                               // per half-step
   constexpr int N_RA = TA ? 2 * FM : FM, N_RB = TB ? 4 * FN : 2 * FN;   // LDS read instructions of fragA / fragB
-  constexpr int N_WRITE = Cfg::A_PASS + (TB ? 1 : 2) * Cfg::B_PASS;
+  constexpr int N_WRITE = Cfg::A_PASS + Cfg::B_PASS;
   auto hint = [&](auto nw_c, auto nr_c) {   // nw LDS writes first, then nr LDS reads, spread over the unit's MFMAs
     constexpr int nw = decltype(nw_c)::value, nr = decltype(nr_c)::value;
     constexpr int per = N_MFMA / (nw + nr) > 0 ? N_MFMA / (nw + nr) : 1;
@@ -512,15 +508,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
         *reinterpret_cast<d2_t*>(as + (p * Cfg::A_RPP + a_tr) * Cfg::LDA_S + a_tc) = v;
       }
 #pragma unroll
-      for (int p = 0; p < Cfg::B_PASS; ++p) {
-        if constexpr (TB) {
-          *reinterpret_cast<d2_t*>(bs + (p * Cfg::B_RPP + b_tr) * Cfg::LDB_S + b_tc) = frb[set][p];
-        } else {   // columns b_tc, b_tc + 1 (b_tc even) land 4 doubles apart in the grouped image
-          double* q = bs + (p * Cfg::B_RPP + b_tr) * Cfg::LDB_S + bpos(b_tc);
-          q[0] = frb[set][p][0];
-          q[4] = frb[set][p][1];
-        }
-      }
+      for (int p = 0; p < Cfg::B_PASS; ++p)
+        *reinterpret_cast<d2_t*>(bs + (p * Cfg::B_RPP + b_tr) * Cfg::LDB_S + b_tc) = frb[set][p];
     };
     if (ktiles > 0) {
       fload(0);
@@ -543,7 +532,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     }
   }
 
-  // ---- epilogue: acc[i][j][e] of lane l is C[rowblk*16 + 4*((l&15)>>2) + (l>>4)][colblk*16 + 4e + (l&3)]
+  // ---- epilogue: acc[i][j][e] of lane l is C[rowblk*16 + 4*((l&15)>>2) + (l>>4)][colblk*16 + 4*(l&3) + e]
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -582,7 +571,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       for (int j = 0; j < FN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const long col = n0 + (long)(j * WC + wc) * 16 + 4 * r + (li & 3);
+          const long col = n0 + (long)(j * WC + wc) * 16 + 4 * (li & 3) + r;
           cfq[j][r] = col < g.N ? g.colf[col * g.rank + q] : 0.0;
         }
 #pragma unroll
@@ -594,6 +583,28 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     }
   }
   const bool atomic = g.splits > 1;
+  if constexpr (FAST && !SCALED) {   // (the scaled kernels sit at the register limit: the extra path made them spill)
+    if (!atomic && !g.beta && g.eadd == nullptr) {
+      // interior tile, 16-byte aligned outputs (host-checked): a lane's four values of a fragment are four
+      // consecutive columns -> two 16-byte stores instead of four scattered 8-byte ones
+      const long o00 = (m0 + (long)wr * 16 + 4 * (li >> 2) + lk) * g.ldc + n0 + (long)wc * 16 + 4 * (li & 3);
+      const long istep = (long)WR * 16 * g.ldc;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const long o = o00 + i * istep + (long)j * WC * 16;
+          d2_t v0 = {acc[i][j][0], acc[i][j][1]}, v1 = {acc[i][j][2], acc[i][j][3]};
+          if (g.C2 != nullptr) {
+            *reinterpret_cast<d2_t*>(g.C2 + o) = v0 * *reinterpret_cast<const d2_t*>(g.emul + o);
+            *reinterpret_cast<d2_t*>(g.C2 + o + 2) = v1 * *reinterpret_cast<const d2_t*>(g.emul + o + 2);
+          }
+          *reinterpret_cast<d2_t*>(C + o) = v0;
+          *reinterpret_cast<d2_t*>(C + o + 2) = v1;
+        }
+      continue;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     double esc = 0.0;
@@ -608,7 +619,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       const long row = m0 + (long)(i * WR + wr) * 16 + 4 * (li >> 2) + lk;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long col = n0 + (long)(j * WC + wc) * 16 + 4 * r + (li & 3);
+        const long col = n0 + (long)(j * WC + wc) * 16 + 4 * (li & 3) + r;
         if (row < g.M && col < g.N) {
           double* p = C + row * g.ldc + col;
           double v = acc[i][j][r];

@@ -74,6 +74,10 @@ static hipError_t dispatch(hipStream_t st, const GemmArgs& a) {
               (a.ascale_mode != 1 || (!TA && a.a_kblk % BK == 0 && a.K % a.a_kblk == 0)) && (a.ascale_mode != 2 || TA) &&
               !(TB && a.ascale_mode != 0) &&
               !(a.ascale_mode == 1 && !a.a_wrap && a.tri != TRI_NONE && a.triblk != a.a_kblk);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+  // the interior kernel stores 16-byte pieces of C (and reads/writes its epilogue companions the same way)
+  if (!(al16(a.C) && a.ldc % 2 == 0 && (a.batch <= 1 || a.sC % 2 == 0) && al16(a.C2) && al16(a.emul) && al16(a.eadd)))
+    fast = false;
   const long Mf = (a.M / BM) * BM;
   if (!TA && a.K % BK != 0) fast = false;        // K is the contiguous direction of A: no K tail handling there
   const long Kf = TA ? (a.K / BK) * BK : a.K;
