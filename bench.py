@@ -65,6 +65,19 @@ def alg_flops_step(N, S, dims, M, Dy):
     return total
 
 
+def survey_per_unit_flops_step(N, S, dims, M, Dy, white=False):
+    """SURVEY.md §8d's per-unit figure (flops per point of a layer, F_fwd(layer)/P, x3 for a step) times the units
+    the launches of one step actually process: N points in the first layer (evaluated once, not per sample),
+    S*N in the others."""
+    w = 1.0 if white else 2.0
+    douts = dims[1:] + [Dy]
+    total = 0.0
+    for l, (din, dout) in enumerate(zip(dims, douts)):
+        per_point = M * (2 * din + 3) + w * M * M + 2 * M * dout + dout * M * (M + 3.0) + 6 * dout
+        total += 3.0 * per_point * (N if l == 0 else float(N) * S)
+    return total
+
+
 def survey_flops_step(N, S, dims, M, Dy, white=False):
     """SURVEY.md §8d's own count, for context: F_step = 3 * sum_layers P*[M(2 D_in + 3) + w M^2 + 2 M D_out +
     D_out M (M+3) + 6 D_out] with P = S*N in EVERY layer and w = 2 solves (non-white).  It credits work this
@@ -182,6 +195,9 @@ def main():
                          "alg_flops_per_step_rank0": mf["alg_flops"] / args.steps,
                          "whole_step_frac": alg_flops_step(args.N, args.S, dims, args.M, 1) / world / (dt / args.steps)
                                             / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                         "frac_by_survey_8d_per_unit_figure": survey_per_unit_flops_step(args.N, args.S, dims, args.M, 1)
+                                                              / world / (mf["ms"] / args.steps * 1e-3) / 1e12
+                                                              / FP64_MFMA_PEAK_TFLOPS,
                          "whole_step_frac_by_survey_8d_count": survey_flops_step(args.N, args.S, dims, args.M, 1) / world
                                                                / (dt / args.steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
             "breakdown_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
