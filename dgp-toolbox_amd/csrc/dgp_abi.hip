@@ -248,7 +248,6 @@ struct LayerFork {
 // their number should fill whole rounds of the resident slots (2 workgroups per CU); `active_tiles` counts the
 // output tiles that survive the triangular skip, times the batch.
 int pick_splits_tiles(dgp_ctx* ctx, long active_tiles, long K, long row_bytes = 0) {
-  (void)ctx; (void)active_tiles;
   // Chunk of points per split sized so that the streamed rows of one chunk (row_bytes each) stay in one XCD's
   // 4 MiB L2 while all members of the chunk read them (see gemm_f64.h: XCD-grouped split-K mapping); the number
   // of splits is a multiple of 8 (one group per XCD at a time).
@@ -265,6 +264,11 @@ int pick_splits_tiles(dgp_ctx* ctx, long active_tiles, long K, long row_bytes = 
   chunk = (chunk / 16) * 16;
   if (chunk < 256) chunk = 256;
   long s = (K + chunk - 1) / chunk;
+  // a launch of few members (skinny outputs, small shards of a multi-GPU run) still has to fill the chip: enough
+  // splits for ~2 workgroups per CU, as long as a split keeps >= 16 k-tiles
+  const long fill = (2L * (ctx->cu_count > 0 ? ctx->cu_count : 256) + active_tiles - 1) / (active_tiles > 0 ? active_tiles : 1);
+  const long cap = K / 256;
+  if (s < fill) s = fill < cap ? fill : cap;
   s = ((s + 7) / 8) * 8;
   if (s * 16 > K) s = 1;                               // tiny reductions: no split
   if (s > 32760) s = 32760;
@@ -329,6 +333,8 @@ void free_model(dgp_ctx* ctx) {
   ctx->segs_uploaded = false;
 }
 
+inline long pad_rows(long P) { return round_up(P, 128); }
+
 // carve the chunk workspace; returns bytes needed.  base == nullptr: size query only
 size_t carve(dgp_ctx* ctx, char* base, long Nc, int S, bool train) {
   size_t off = 0;
@@ -338,32 +344,36 @@ size_t carve(dgp_ctx* ctx, char* base, long Nc, int S, bool train) {
     return p;
   };
   const int nl = (int)ctx->L.size();
+  // Row counts of everything a row-parallel GEMM reads or writes are rounded up to the GEMM row tile (pad_rows):
+  // the products then run on whole tiles (no predicated edge strip: a 128-row strip of a K = D*Mp product is a
+  // 0.25 ms serial tail at multi-GPU shard sizes).  The pad rows hold garbage that never enters a reduction
+  // (those run over exactly Pl rows).
   long Pmax_Mp = 0, pl_max = 0, xb_max = 0, x1_max = 0;
   for (int l = 0; l < nl; ++l) {
     Layer& y = ctx->L[l];
-    const long Pl = (l == 0) ? Nc : (long)S * Nc;
-    Pmax_Mp = std::max(Pmax_Mp, Pl * y.Mp);
-    pl_max = std::max(pl_max, Pl * (y.Mp / 32) * (1 + y.d.D_out));
+    const long Pl = (l == 0) ? Nc : (long)S * Nc, Pm = pad_rows(Pl);
+    Pmax_Mp = std::max(Pmax_Mp, Pm * y.Mp);
+    pl_max = std::max(pl_max, Pm * (y.Mp / 32) * (1 + y.d.D_out));
     xb_max = std::max(xb_max, (long)S * Nc * y.d.D_in);
-    x1_max = std::max(x1_max, Pl * (y.d.D_in + 1));
+    x1_max = std::max(x1_max, Pm * (y.d.D_in + 1));
   }
   double *sKt = nullptr, *sCt = nullptr, *sPl = nullptr;
   if (!train) { sKt = take(Pmax_Mp); sCt = take(Pmax_Mp); }
   sPl = take(pl_max);                                      // row-norm partial planes: consumed within the layer
   for (int l = 0; l < nl; ++l) {
     Layer& y = ctx->L[l];
-    const long Pl = (l == 0) ? Nc : (long)S * Nc;
+    const long Pl = (l == 0) ? Nc : (long)S * Nc, Pm = pad_rows(Pl);
     const long D = y.d.D_out;
-    if (train) { y.Kt = take(Pl * y.Mp); y.Ct = take(Pl * y.Mp); }
+    if (train) { y.Kt = take(Pm * y.Mp); y.Ct = take(Pm * y.Mp); }
     else { y.Kt = sKt; y.Ct = sCt; }
     y.cnp = sPl;
-    y.tnp = sPl ? sPl + Pl * (y.Mp / 32) : nullptr;
-    y.mean0 = take(Pl * D); y.mean = take(Pl * D); y.var = take(Pl * D);
+    y.tnp = sPl ? sPl + Pm * (y.Mp / 32) : nullptr;
+    y.mean0 = take(Pm * D); y.mean = take(Pl * D); y.var = take(Pl * D);
     y.F = take((long)S * Nc * D);
-    if (train) { y.mbar = take(Pl * D); y.vbar = take(Pl * D); }
+    if (train) { y.mbar = take(Pm * D); y.vbar = take(Pm * D); }
     else { y.mbar = y.vbar = nullptr; }
-    y.Tt = (train && ctx->store_t) ? take(Pl * D * y.Mp) : nullptr;
-    y.Et = (train && y.d.kernel_kind != DGP_KERNEL_RBF) ? take(Pl * y.Mp) : nullptr;
+    y.Tt = (train && ctx->store_t) ? take(Pm * D * y.Mp) : nullptr;
+    y.Et = (train && y.d.kernel_kind != DGP_KERNEL_RBF) ? take(Pm * y.Mp) : nullptr;
   }
   if (train) {
     ctx->Cbar = take(Pmax_Mp); ctx->Kbar = take(Pmax_Mp); ctx->Gt = take(Pmax_Mp); ctx->xbar = take(xb_max);
@@ -459,7 +469,7 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
     Layer& y = ctx->L[l];
     const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
     const bool dedup = (l == 0);
-    const long Pl = dedup ? Nc : (long)S * Nc;
+    const long Pl = dedup ? Nc : (long)S * Nc, Pm = pad_rows(Pl);
     const double* Xin = dedup ? Xsrc : ctx->L[l - 1].F;
     const long row0 = dedup ? n0 : 0;
     const int nplane = Mp / 32;
@@ -470,19 +480,19 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
     }
     const double tri1 = (double)Pl * Mp * (Mp + 1.0);   // 2 * M(M+1)/2 flops per point
     {  // c = Lu^-1 k  and |c|^2 partials
-      GemmArgs a = mk(Pl, Mp, Mp, y.Kt, Mp, y.Linv, Mp, y.Ct, Mp);
-      a.tri = TRI_B_UPPER; a.triblk = Mp; a.epi = 2; a.rowsq = y.cnp; a.rowsq_ld = Pl;
+      GemmArgs a = mk(Pm, Mp, Mp, y.Kt, Mp, y.Linv, Mp, y.Ct, Mp);
+      a.tri = TRI_B_UPPER; a.triblk = Mp; a.epi = 2; a.rowsq = y.cnp; a.rowsq_ld = Pm;
       RET(GX(ctx, 0, GEMM_NT, a, tri1, (double)Pl * Mp * 16));
     }
     {  // t_d = W_d^T c: |t_d|^2 partials always leave the kernel; t_d itself only for the backward pass (store_t)
-      GemmArgs a = mk(Pl, (long)D * Mp, Mp, y.Ct, Mp, y.Wcat, (long)D * Mp, y.Tt, (long)D * Mp);
-      a.tri = TRI_B_LOWER; a.triblk = Mp; a.epi = y.Tt ? 2 : 1; a.rowsq = y.tnp; a.rowsq_ld = Pl;
+      GemmArgs a = mk(Pm, (long)D * Mp, Mp, y.Ct, Mp, y.Wcat, (long)D * Mp, y.Tt, (long)D * Mp);
+      a.tri = TRI_B_LOWER; a.triblk = Mp; a.epi = y.Tt ? 2 : 1; a.rowsq = y.tnp; a.rowsq_ld = Pm;
       RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 8 * (y.Tt ? 1 + D : 1)));
     }
-    RET(GX(ctx, 0, GEMM_NN, mk(Pl, D, Mp, y.Ct, Mp, y.u, D, y.mean0, D), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
+    RET(GX(ctx, 0, GEMM_NN, mk(Pm, D, Mp, y.Ct, Mp, y.u, D, y.mean0, D), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
     {
       ProfScope ps(ctx, 1, 0, (double)Pl * nplane * 8 * (1 + D));
-      HIPCHK(finalize_layer(ctx->st, y.cnp, y.tnp, nplane, y.mean0, Xin, row0, Pl, Nc, S, dedup ? 1 : 0, Din, D,
+      HIPCHK(finalize_layer(ctx->st, y.cnp, y.tnp, nplane, Pm, y.mean0, Xin, row0, Pl, Nc, S, dedup ? 1 : 0, Din, D,
                             P(ctx, y.off_var), y.d.mean_kind, y.meanW, y.meanb,
                             zsrc_of(ctx, l, use_zs, seed, n_goff, Ntot), n0, y.mean, y.var, y.F));
     }
@@ -509,27 +519,27 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     Layer& y = ctx->L[l];
     const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
     const bool dedup = (l == 0);
-    const long Pl = dedup ? Nc : (long)S * Nc;
+    const long Pl = dedup ? Nc : (long)S * Nc, Pm = pad_rows(Pl);
     const double* Xin = dedup ? o.X : ctx->L[l - 1].F;
     const long row0 = dedup ? n0 : 0;
     const long DM = (long)D * Mp, MM = (long)Mp * Mp;
     const double tri1 = (double)Pl * Mp * (Mp + 1.0);
     if (y.Tt) {  // dC = sum_d 2 vbar_d (W_d t_d - c): [2 vbar .* T] * WTcat, W_d lower => k <= n per block; "- c" in the epilogue
-      GemmArgs a = mk(Pl, Mp, DM, y.Tt, DM, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);
+      GemmArgs a = mk(Pm, Mp, DM, y.Tt, DM, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);
       a.ascale = y.vbar; a.as_ld = D; a.a_kblk = Mp; a.ascale_mode = 1; a.a_wrap = 0;
       a.tri = TRI_B_UPPER; a.triblk = Mp;
       a.eadd = y.Ct; a.eadd_nsc = D;
       a.rowf = y.mbar; a.colf = y.u; a.rank = D;             // + mbar u^T in the epilogue
       RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 8 * (2 + D)));
     } else {  // dC = sum_d 2 vbar_d .* (C S'_d)      (A operand scaled on the fly; K = D*Mp re-reads C per block)
-      GemmArgs a = mk(Pl, Mp, DM, y.Ct, Mp, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);
+      GemmArgs a = mk(Pm, Mp, DM, y.Ct, Mp, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);
       a.ascale = y.vbar; a.as_ld = D; a.a_kblk = Mp; a.ascale_mode = 1;
       a.rowf = y.mbar; a.colf = y.u; a.rank = D;             // + mbar u^T in the epilogue
       // algorithmic count: the D triangular products W_d t_d of SURVEY App. C (the dense S' form executes 2x that)
       RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 16));
     }
     {
-      GemmArgs a = mk(Pl, Mp, Mp, ctx->Cbar, Mp, y.Linv, Mp, ctx->Kbar, Mp);
+      GemmArgs a = mk(Pm, Mp, Mp, ctx->Cbar, Mp, y.Linv, Mp, ctx->Kbar, Mp);
       a.tri = TRI_B_LOWER; a.triblk = Mp;
       a.emul = y.Et ? y.Et : y.Kt; a.C2 = ctx->Gt;          // g = dK .* e (e = -2 dk/dr2; = k for the squared exponential)
       RET(GX(ctx, 0, GEMM_NN, a, tri1, (double)Pl * Mp * 32));
@@ -559,7 +569,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
         ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 16);
         HIPCHK(make_x1(ctx->st, Xin, row0, Pl, Din, ctx->X1));
       }
-      RET(GX(ctx, 0, GEMM_NN, mk(Pl, w1, Mp, ctx->Gt, Mp, y.Z1, w1, ctx->R1, w1), 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
+      RET(GX(ctx, 0, GEMM_NN, mk(Pm, w1, Mp, ctx->Gt, Mp, y.Z1, w1, ctx->R1, w1), 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
       if (o.params) {
         GemmArgs a = mk(Mp, w1, Pl, ctx->Gt, Mp, ctx->X1, w1, acc + y.acc_GX, w1, 1.0, 1);
         a.splits = pick_splits(ctx, Mp, w1, Pl);

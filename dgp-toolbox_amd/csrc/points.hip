@@ -135,7 +135,8 @@ hipError_t rbf_kuf(hipStream_t st, int kind, const double* Xin, long P, long x_r
 //   F = mean + z sqrt(var + jitter)      (utils.py:41)
 // One thread per (d, p), p fastest (coalesced plane reads).
 __global__ __launch_bounds__(256) void finalize_layer_kernel(
-    const double* __restrict__ cnp, const double* __restrict__ tnp, int nplane, const double* __restrict__ mean0,
+    const double* __restrict__ cnp, const double* __restrict__ tnp, int nplane, long pstride,
+    const double* __restrict__ mean0,
     const double* __restrict__ Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
     const double* __restrict__ kvar, int mean_kind, const double* __restrict__ meanW, const double* __restrict__ meanb,
     ZSource zsrc, long n_chunk0, double* __restrict__ mean, double* __restrict__ var, double* __restrict__ F) {
@@ -145,8 +146,8 @@ __global__ __launch_bounds__(256) void finalize_layer_kernel(
   const long p = idx % P;
   double cn = 0.0, tn = 0.0;
   for (int q = 0; q < nplane; ++q) {
-    cn += cnp[(long)q * P + p];
-    tn += tnp[((long)d * nplane + q) * P + p];
+    cn += cnp[(long)q * pstride + p];
+    tn += tnp[((long)d * nplane + q) * pstride + p];
   }
   const double* x = Xin + (x_row0 + p) * Din;
   double mf = 0.0;
@@ -170,13 +171,14 @@ __global__ __launch_bounds__(256) void finalize_layer_kernel(
   }
 }
 
-hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, int nplane, const double* mean0,
+hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, int nplane, long pstride,
+                          const double* mean0,
                           const double* Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
                           const double* kvar, int mean_kind, const double* meanW, const double* meanb, ZSource zsrc,
                           long n_chunk0, double* mean, double* var, double* F) {
   const long n = P * D;
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(finalize_layer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cnp, tnp, nplane, mean0, Xin,
+  hipLaunchKernelGGL(finalize_layer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cnp, tnp, nplane, pstride, mean0, Xin,
                      x_row0, P, Nc, S, dedup, Din, D, kvar, mean_kind, meanW, meanb, zsrc, n_chunk0, mean, var, F);
   LAUNCH_CHECK();
 }
