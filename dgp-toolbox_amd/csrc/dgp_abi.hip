@@ -247,7 +247,7 @@ struct LayerFork {
 // Split-K factor for the reductions over points: all active workgroups of such a launch run equally long, so
 // their number should fill whole rounds of the resident slots (2 workgroups per CU); `active_tiles` counts the
 // output tiles that survive the triangular skip, times the batch.
-int pick_splits_tiles(dgp_ctx* ctx, long active_tiles, long K, long row_bytes = 0) {
+int pick_splits_tiles(dgp_ctx* ctx, long active_tiles, long K, long row_bytes = 0, long min_rows = 2048) {
   // Chunk of points per split sized so that the streamed rows of one chunk (row_bytes each) stay in one XCD's
   // 4 MiB L2 while all members of the chunk read them (see gemm_f64.h: XCD-grouped split-K mapping); the number
   // of splits is a multiple of 8 (one group per XCD at a time).
@@ -265,9 +265,10 @@ int pick_splits_tiles(dgp_ctx* ctx, long active_tiles, long K, long row_bytes = 
   if (chunk < 256) chunk = 256;
   long s = (K + chunk - 1) / chunk;
   // a launch of few members (skinny outputs, small shards of a multi-GPU run) still has to fill the chip: enough
-  // splits for ~2 workgroups per CU, as long as a split keeps >= 16 k-tiles
+  // splits for ~2 workgroups per CU, as long as a split keeps >= min_rows of K (the atomics of a split cost a
+  // full tile of traffic: 2048 rows for 128x64 tiles, 256 for the skinny 128x16 ones)
   const long fill = (2L * (ctx->cu_count > 0 ? ctx->cu_count : 256) + active_tiles - 1) / (active_tiles > 0 ? active_tiles : 1);
-  const long cap = K / 256;
+  const long cap = K / min_rows;
   if (s < fill) s = fill < cap ? fill : cap;
   s = ((s + 7) / 8) * 8;
   if (s * 16 > K) s = 1;                               // tiny reductions: no split
@@ -286,7 +287,7 @@ long lower_tiles(long Mp) {
 
 int pick_splits(dgp_ctx* ctx, long Mrows, long Ncols, long K) {
   const long tiles = ((Mrows + 127) / 128) * ((Ncols + 63) / 64);
-  return pick_splits_tiles(ctx, tiles, K, Mrows * 8);
+  return pick_splits_tiles(ctx, tiles, K, Mrows * 8, Ncols <= 16 ? 256 : 2048);
 }
 
 // ------------------------------------------------------------------------------- memory helpers
