@@ -67,6 +67,7 @@ struct GemmArgs {
   // optional row scaling of the physical A tile (fused elementwise work, no extra HBM pass):
   //   ascale_mode 1 (A not transposed): A[m][k] = ascale[m*as_ld + k / a_kblk] * Aphys[m][k % a_kblk]
   //                                     (K = nblk * a_kblk re-reads the same physical columns per block)
+  //                                     a_wrap = 2: as 1, block index innermost on the interior path (see there)
   //                                     a_wrap = 0: A is stored with all K columns (no re-reading): A[m][k] =
   //                                     ascale[m*as_ld + k / a_kblk] * Aphys[m][k]; with a triangular hint the
   //                                     host passes triblk == a_kblk (scale blocks = triangular blocks)
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       else
         tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, k0, m0, kend, g.M, tid);
     } else {
-      if (g.ascale_mode == 1 && g.a_wrap) {                // BK divides a_kblk: a k-tile never straddles blocks
+      if (g.ascale_mode == 1 && g.a_wrap) {                // (a_wrap 2 = 1 here: only the summation order differs)
+                                                           // BK divides a_kblk: a k-tile never straddles blocks
         tile_load<Cfg::A_ROWS, Cfg::A_COLS, VA, Cfg::A_TPR, Cfg::A_RPP, Cfg::A_PASS>(ra, A, g.lda, m0, cur_aoff, g.M, g.a_kblk, tid,
                                                                                       g.ascale, g.as_ld, cur_ablk);
       } else if (g.ascale_mode == 1) {                     // all K columns stored; scale block = k0 / a_kblk
@@ -441,11 +443,17 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     static_assert(!FAST || (VA == 2 && VB == 2), "fast path is vectorised");
     const int a_tr = tid / Cfg::A_TPR, a_tc = (tid % Cfg::A_TPR) * 2;
     const int b_tr = tid / Cfg::B_TPR, b_tc = (tid % Cfg::B_TPR) * 2;
-    const bool wrap = (!TA) && SCALED && g.a_wrap;             // ascale_mode 1: K wraps around a_kblk physical columns
-    const bool blk_scale = (!TA) && SCALED && !g.a_wrap;       // ... or A holds all K columns: the scale follows the k-blocks
+    const bool wrap = (!TA) && SCALED && g.a_wrap == 1;        // ascale_mode 1: K wraps around a_kblk physical columns
+    // a_wrap == 2: the same product with the block index INNERMOST (k = kk_tile, then d = 0..nblk-1): the A tile of
+    // a k-chunk is fetched nblk times back to back (cache hits) instead of once per pass over the whole row block,
+    // which at 16 row blocks x 256 KB per XCD overflowed the 4 MB L2 (the dC launch fetched 9x its operand from HBM)
+    const bool wrap2 = (!TA) && SCALED && g.a_wrap == 2;
+    const long nblk = wrap2 ? g.K / g.a_kblk : 1;
+    long d_idx = 0;
+    const bool blk_scale = (!TA) && SCALED && g.a_wrap == 0;       // ... or A holds all K columns: the scale follows the k-blocks
     // Addressing: one wave-uniform base pointer per operand (scalar registers, advanced per k-tile) plus constant
     // 32-bit per-lane byte offsets, so that the loads use the scalar-base form and no 64-bit vector adds.
-    const char* ua = reinterpret_cast<const char*>(TA ? A + klo * g.lda + m0 : A + m0 * g.lda + (wrap ? 0 : klo));
+    const char* ua = reinterpret_cast<const char*>(TA ? A + klo * g.lda + m0 : A + m0 * g.lda + ((wrap || wrap2) ? 0 : klo));
     const char* ub = reinterpret_cast<const char*>(TB ? B + n0 * g.ldb + klo : B + klo * g.ldb + n0);
     unsigned offa[Cfg::A_PASS], offb[Cfg::B_PASS], offs[Cfg::A_PASS];
 #pragma unroll
@@ -493,6 +501,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       if (wrap) {
         kk_in_wrap += 1;
         if (kk_in_wrap == tiles_per_wrap) { kk_in_wrap = 0; ka = BK - g.a_kblk; if constexpr (SCALED) us += 8; }
+      }
+      if (wrap2) {
+        d_idx += 1;
+        ka = 0; kbs = g.a_kblk;                              // same A columns, next block of B
+        long sadv = 8;
+        if (d_idx == nblk) { d_idx = 0; ka = BK; kbs = BK - (nblk - 1) * g.a_kblk; sadv = -(nblk - 1) * 8; }
+        if constexpr (SCALED) us += sadv;
       }
       ua += ka * a_kstride;
       ub += kbs * b_kstride;
