@@ -879,6 +879,88 @@ int dgp_propagate(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint6
   return check_flags(ctx);
 }
 
+int dgp_propagate_full_cov(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed,
+                           const double* const* zs, double* const* Fs, double* const* Fmeans, double* const* Fvars) {
+  RET(check_ready(ctx, false));
+  if (!Xnew || Nn <= 0 || S <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_propagate_full_cov: bad arguments");
+  if (Nn > 1024) return fail(ctx, DGP_ERR_INVALID, "dgp_propagate_full_cov: at most 1024 points (N x N covariances per sample)");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nl = (int)ctx->L.size();
+  const long N = Nn, Pm = pad_rows(N);
+  const int Np = (int)round_up(N, 64);
+  if (zs) RET(upload_zs(ctx, zs, S, N));
+  RET(prep(ctx));
+  int Dmax = 1, Mpmax = 64, Dinmax = 1;
+  for (auto& y : ctx->L) { Dmax = std::max(Dmax, y.d.D_out); Mpmax = std::max(Mpmax, y.Mp); Dinmax = std::max(Dinmax, y.d.D_in); }
+  // scratch for one sample of one layer (small-N path: allocated per call)
+  double *Kt = nullptr, *Ct = nullptr, *T = nullptr, *mean0 = nullptr, *mean = nullptr, *Kff = nullptr, *V = nullptr,
+         *Vinv = nullptr, *tmp = nullptr, *var_dev = nullptr, *Fa = nullptr, *Fb = nullptr, *X0 = nullptr;
+  const long NN = (long)Np * Np;
+  struct Free {
+    std::vector<double**> ps;
+    ~Free() { for (auto p : ps) dev_free(*p); }
+  } guard;
+  auto get = [&](double** p, long n) -> int { guard.ps.push_back(p); return dev_alloc(ctx, p, (size_t)n); };
+  RET(get(&Kt, Pm * Mpmax)); RET(get(&Ct, Pm * Mpmax)); RET(get(&T, Pm * (long)Dmax * Mpmax));
+  RET(get(&mean0, Pm * Dmax)); RET(get(&mean, N * Dmax)); RET(get(&Kff, NN)); RET(get(&V, NN * Dmax));
+  RET(get(&Vinv, NN * Dmax)); RET(get(&tmp, NN * Dmax)); RET(get(&var_dev, N * N * Dmax));
+  RET(get(&Fa, (long)S * N * std::max(Dmax, Dinmax))); RET(get(&Fb, (long)S * N * std::max(Dmax, Dinmax)));
+  RET(get(&X0, N * ctx->L[0].d.D_in));
+  HIPCHK(hipMemcpyAsync(X0, Xnew, (size_t)N * ctx->L[0].d.D_in * 8, hipMemcpyHostToDevice, ctx->st));
+  double *Fin = Fa, *Fout = Fb;
+  for (int l = 0; l < nl; ++l) {
+    Layer& y = ctx->L[l];
+    const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
+    (void)M;
+    const long DM = (long)D * Mp;
+    const ZSource zsrc = zsrc_of(ctx, l, zs != nullptr, seed, 0, N);
+    for (int s = 0; s < S; ++s) {
+      const double* Xs = (l == 0) ? X0 : Fin + (long)s * N * Din;
+      HIPCHK(hipMemsetAsync(Kt, 0, (size_t)Pm * Mp * 8, ctx->st));            // pad rows of every product stay zero
+      HIPCHK(rbf_kuf(ctx->st, y.d.kernel_kind, Xs, N, 0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), y.d.M, Mp, Din,
+                     Kt, nullptr));
+      {
+        GemmArgs a = mk(Pm, Mp, Mp, Kt, Mp, y.Linv, Mp, Ct, Mp);
+        a.tri = TRI_B_UPPER; a.triblk = Mp;
+        RET(GX(ctx, 0, GEMM_NT, a));
+      }
+      {
+        GemmArgs a = mk(Pm, DM, Mp, Ct, Mp, y.Wcat, DM, T, DM);
+        a.tri = TRI_B_LOWER; a.triblk = Mp;
+        RET(GX(ctx, 0, GEMM_NN, a));
+      }
+      RET(GX(ctx, 0, GEMM_NN, mk(Pm, D, Mp, Ct, Mp, y.u, D, mean0, D)));
+      HIPCHK(fc_mean(ctx->st, mean0, Xs, N, Din, D, y.d.mean_kind, y.meanW, y.meanb, mean));
+      // V_d = K(X_s, X_s) + jitter I - C C^T + T_d T_d^T   (layers.py:265-268 in whitened form; jitter: utils.py:47)
+      HIPCHK(rbf_kuu(ctx->st, y.d.kernel_kind, Xs, P(ctx, y.off_var), P(ctx, y.off_ls), (int)N, Np, Din, Kff, nullptr));
+      for (int d = 0; d < D; ++d) HIPCHK(copy_mat(ctx->st, Kff, V + (long)d * NN, NN));
+      {
+        GemmArgs a = mk(Np, Np, Mp, Ct, Mp, Ct, Mp, V, Np, -1.0, 1);
+        a.batch = D; a.sA = 0; a.sB = 0; a.sC = NN;
+        RET(GX(ctx, 0, GEMM_NT, a));
+      }
+      {
+        GemmArgs a = mk(Np, Np, Mp, T, DM, T, DM, V, Np, 1.0, 1);
+        a.batch = D; a.sA = Mp; a.sB = Mp; a.sC = NN;
+        RET(GX(ctx, 0, GEMM_NT, a));
+      }
+      if (Fvars && Fvars[l]) {
+        HIPCHK(fc_export_var(ctx->st, V, N, Np, D, var_dev));
+        HIPCHK(hipMemcpyAsync(Fvars[l] + (long)s * N * N * D, var_dev, (size_t)N * N * D * 8, hipMemcpyDeviceToHost, ctx->st));
+      }
+      if (Fmeans && Fmeans[l])
+        HIPCHK(hipMemcpyAsync(Fmeans[l] + (long)s * N * D, mean, (size_t)N * D * 8, hipMemcpyDeviceToHost, ctx->st));
+      HIPCHK(potrf_inv(ctx->st, V, Vinv, tmp, Np, D, ctx->info));
+      HIPCHK(fc_sample(ctx->st, V, mean, N, Np, D, zsrc, s, Fout + (long)s * N * D));
+      if (Fvars && Fvars[l]) HIPCHK(hipStreamSynchronize(ctx->st));           // var_dev is reused by the next sample
+    }
+    if (Fs && Fs[l])
+      HIPCHK(hipMemcpyAsync(Fs[l], Fout, (size_t)S * N * D * 8, hipMemcpyDeviceToHost, ctx->st));
+    std::swap(Fin, Fout);
+  }
+  return check_flags(ctx);
+}
+
 int dgp_propagate_vjp(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
                       const double* f_bar, const double* mean_bar, const double* var_bar, double* xbar_out) {
   RET(check_ready(ctx, false));

@@ -117,6 +117,13 @@ hipError_t xbar_finish(hipStream_t st, const double* R1, const double* X1, long 
 hipError_t expand_rows(hipStream_t st, const double* src, long Nc, int S, int D, int dedup, double* dst, long Ntot,
                        long n0);
 hipError_t lik_predict_var(hipStream_t st, double* var, long n, const double* lik_var);
+// full-covariance pieces (one sample at a time, small N): layers.py:77-80,265-268; utils.py:43-51
+hipError_t fc_mean(hipStream_t st, const double* mean0, const double* X, long N, int Din, int D, int mean_kind,
+                   const double* meanW, const double* meanb, double* mean);
+hipError_t fc_export_var(hipStream_t st, const double* V /* [D][Np][Np], jitter on the diagonal */, long N, int Np, int D,
+                         double* var_out /* [N][N][D] */);
+hipError_t fc_sample(hipStream_t st, const double* L /* [D][Np][Np] */, const double* mean, long N, int Np, int D,
+                     ZSource zsrc, int s, double* F);
 hipError_t launch_normals(hipStream_t st, ZSource z, int S, long N, int D, double* out);
 hipError_t launch_mfma_peak(hipStream_t st, int blocks, int iters, double* sink);
 

@@ -427,6 +427,60 @@ hipError_t lik_predict_var(hipStream_t st, double* var, long n, const double* li
   LAUNCH_CHECK();
 }
 
+// ---------------------------------------------------------------------------------------- full covariance (small N)
+// Pieces of the full_cov=True branches of layers.py:77-80,265-268 and utils.py:43-51, one sample s at a time.
+// mean[i][d] = mean0[i][d] + mean_function(x_i)
+__global__ void fc_mean_kernel(const double* __restrict__ mean0, const double* __restrict__ X, long N, int Din, int D,
+                               int mean_kind, const double* __restrict__ meanW, const double* __restrict__ meanb,
+                               double* __restrict__ mean) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * D) return;
+  const long i = idx / D;
+  const int d = (int)(idx % D);
+  double mf = 0.0;
+  if (mean_kind == 1) mf = X[i * Din + d];
+  else if (mean_kind == 2) {
+    for (int j = 0; j < Din; ++j) mf += X[i * Din + j] * meanW[(long)j * D + d];
+    mf += meanb[d];
+  }
+  mean[idx] = mean0[idx] + mf;
+}
+// var_out[i][j][d] = V_d[i][j] - jitter * (i == j)      (V carries the jitter of utils.py:47 for its Cholesky)
+__global__ void fc_export_var_kernel(const double* __restrict__ V, long N, int Np, int D, double* __restrict__ var_out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * N * D) return;
+  const int d = (int)(idx % D);
+  const long ij = idx / D, i = ij / N, j = ij % N;
+  var_out[idx] = V[((long)d * Np + i) * Np + j] - (i == j ? kJitter : 0.0);
+}
+// F[i][d] = mean[i][d] + sum_{j <= i} L_d[i][j] z[s][j][d]
+__global__ void fc_sample_kernel(const double* __restrict__ L, const double* __restrict__ mean, long N, int Np, int D,
+                                 ZSource zsrc, int s, double* __restrict__ F) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * D) return;
+  const long i = idx / D;
+  const int d = (int)(idx % D);
+  const double* Ld = L + ((long)d * Np + i) * Np;
+  double a = mean[idx];
+  for (long j = 0; j <= i; ++j) a += Ld[j] * draw_z(zsrc, s, j, d, D);
+  F[idx] = a;
+}
+hipError_t fc_mean(hipStream_t st, const double* mean0, const double* X, long N, int Din, int D, int mean_kind,
+                   const double* meanW, const double* meanb, double* mean) {
+  hipLaunchKernelGGL(fc_mean_kernel, dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, st, mean0, X, N, Din, D, mean_kind,
+                     meanW, meanb, mean);
+  LAUNCH_CHECK();
+}
+hipError_t fc_export_var(hipStream_t st, const double* V, long N, int Np, int D, double* var_out) {
+  hipLaunchKernelGGL(fc_export_var_kernel, dim3((unsigned)((N * N * D + 255) / 256)), dim3(256), 0, st, V, N, Np, D, var_out);
+  LAUNCH_CHECK();
+}
+hipError_t fc_sample(hipStream_t st, const double* L, const double* mean, long N, int Np, int D, ZSource zsrc, int s,
+                     double* F) {
+  hipLaunchKernelGGL(fc_sample_kernel, dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, st, L, mean, N, Np, D, zsrc, s, F);
+  LAUNCH_CHECK();
+}
+
 // ---------------------------------------------------------------------------------------- unit-level helpers
 __global__ void normals_kernel(ZSource z, int S, long N, int D, double* __restrict__ out) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -20,7 +20,7 @@ DGP_OK, ERR_INVALID, ERR_HIP, ERR_NOT_PD, ERR_NO_DEVICE, ERR_NONFINITE = 0, -1, 
 SYMBOLS = [
     "dgp_create", "dgp_destroy", "dgp_last_error", "dgp_sync", "dgp_device_info", "dgp_model_set", "dgp_param_count",
     "dgp_params_get", "dgp_params_set", "dgp_data_set", "dgp_set_workspace_limit", "dgp_elbo", "dgp_propagate",
-    "dgp_propagate_vjp",
+    "dgp_propagate_vjp", "dgp_propagate_full_cov",
     "dgp_grad_partial", "dgp_acc_info", "dgp_acc_bind", "dgp_grad_finish", "dgp_grad_get", "dgp_last_elbo",
     "dgp_adam_reset", "dgp_adam_step", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_dev_gemm",
     "dgp_dev_chol", "dgp_dev_trinv", "dgp_dev_normals", "dgp_dev_mfma_peak",
@@ -77,6 +77,7 @@ def load():
         "dgp_elbo": (C.c_int, [vp, i32, u64, _dpp, _dp, _dp]),
         "dgp_propagate": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dpp, _dpp, _dpp, i32]),
         "dgp_propagate_vjp": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dp, _dp, _dp, _dp]),
+        "dgp_propagate_full_cov": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dpp, _dpp, _dpp]),
         "dgp_grad_partial": (C.c_int, [vp, i32, u64, _dpp]),
         "dgp_acc_info": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "dgp_acc_bind": (C.c_int, [vp, vp]),
@@ -202,6 +203,18 @@ class Context:
         self._chk(self._lib.dgp_propagate(self._h, _ptr(Xnew), Nn, int(S), int(seed) & (2 ** 64 - 1), zp, ptrs[0],
                                           ptrs[1], ptrs[2], 1 if add_lik_var else 0))
         return outs
+
+    def propagate_full_cov(self, Xnew, S, seed=0, zs=None):
+        """full_cov=True propagation (dgp_propagate_full_cov): Fvars are [S, Nn, Nn, D_l]."""
+        Xnew = _c(Xnew)
+        Nn = Xnew.shape[0]
+        zp, keep = self._zs(zs)
+        Fs = [np.empty((S, Nn, d)) for d in self.douts]
+        Fm = [np.empty((S, Nn, d)) for d in self.douts]
+        Fv = [np.empty((S, Nn, Nn, d)) for d in self.douts]
+        self._chk(self._lib.dgp_propagate_full_cov(self._h, _ptr(Xnew), Nn, int(S), int(seed) & (2 ** 64 - 1), zp,
+                                                   _ptr_array(Fs), _ptr_array(Fm), _ptr_array(Fv)))
+        return Fs, Fm, Fv
 
     def propagate_vjp(self, Xnew, S, seed=0, zs=None, f_bar=None, mean_bar=None, var_bar=None):
         """d(sum of cotangent * last-layer output)/dXnew, [Nn, D_in] (dgp_propagate_vjp)."""

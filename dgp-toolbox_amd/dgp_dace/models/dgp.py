@@ -134,11 +134,12 @@ class DGP_Base:
     # ------------------------------------------------------------------ forward API (dgp.py:34-124)
     def propagate(self, X, full_cov=False, S=1, zs=None):
         """Propagate the inputs through all the layers: returns (Fs, Fmeans, Fvars), one [S,N,D_l] each per layer."""
-        if full_cov:
-            raise NotImplementedError("full_cov=True (layers.py:77-80,265-268) is a listed next row, not implemented")
         ctx = self._sync_model()
         X = np.asarray(X.numpy() if hasattr(X, "numpy") else X, dtype=np.float64)
-        Fs, Fm, Fv = ctx.propagate(X, int(S), self._next_seed(), zs)
+        if full_cov:        # N x N covariance per sample and output, samples through its Cholesky (small-N path)
+            Fs, Fm, Fv = ctx.propagate_full_cov(X, int(S), self._next_seed(), zs)
+        else:
+            Fs, Fm, Fv = ctx.propagate(X, int(S), self._next_seed(), zs)
         return [as_tensor(a) for a in Fs], [as_tensor(a) for a in Fm], [as_tensor(a) for a in Fv]
 
     def propagate_vjp(self, X, S=1, f_bar=None, mean_bar=None, var_bar=None, zs=None, seed=None):
@@ -155,7 +156,8 @@ class DGP_Base:
 
     def predict_f(self, X, full_cov=False, S=1):
         if full_cov:
-            raise NotImplementedError("full_cov=True is a listed next row, not implemented")
+            _, Fm, Fv = self.propagate(X, full_cov=True, S=S)
+            return Fm[-1], Fv[-1]
         ctx = self._sync_model()
         X = np.asarray(X.numpy() if hasattr(X, "numpy") else X, dtype=np.float64)
         nl = len(self.layers)

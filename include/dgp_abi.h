@@ -86,6 +86,12 @@ int dgp_elbo(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs, do
 int dgp_propagate(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
                   double* const* Fs, double* const* Fmeans, double* const* Fvars, int32_t add_lik_var);
 
+/* the full_cov=True branches of the same calls (layers.py:77-80,265-268; utils.py:43-51): per sample s and output d
+ * the N x N covariance over the Nn points, samples drawn through its Cholesky factor (jitter 1e-6 as the reference).
+ * Fvars entries are [S,Nn,Nn,D_out_l]; Fs / Fmeans as in dgp_propagate.  Small-N path: Nn <= 1024.             */
+int dgp_propagate_full_cov(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed,
+                           const double* const* zs, double* const* Fs, double* const* Fmeans, double* const* Fvars);
+
 /* vector-Jacobian product of dgp_propagate with respect to Xnew: replaces `tape.gradient(objective, x)` on the
  * acquisition side (Infill_criteria.py:79-85, where the objective is a function of predict_f / propagate outputs).
  * f_bar, mean_bar, var_bar: cotangents of the LAST layer's sample F, Fmean and Fvar, host [S,Nn,D_out_L] each

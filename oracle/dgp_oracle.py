@@ -129,8 +129,8 @@ class OracleLayer:
         self.Ku = self.kern.K(self.Z) + JITTER * np.eye(self.num_inducing)
         self.Lu = np.linalg.cholesky(self.Ku)
 
-    # layers.py:237-278 (full_cov=False branch)
-    def conditional_ND(self, X):
+    # layers.py:237-278
+    def conditional_ND(self, X, full_cov=False):
         self.build_cholesky()
         Kuf = self.kern.K(self.Z, X)                                     # :243  [M,P]
         A = sla.solve_triangular(self.Lu, Kuf, lower=True)               # :245
@@ -142,20 +142,34 @@ class OracleLayer:
         SK = -I if self.white else -np.tile(self.Ku[None], [self.num_outputs, 1, 1])
         SK = SK + self.q_sqrt @ np.transpose(self.q_sqrt, (0, 2, 1))     # :260
         B = SK @ A_tiled                                                 # :263
+        if full_cov:
+            delta_cov = np.transpose(A_tiled, (0, 2, 1)) @ B             # :267  [D,P,P]
+            Kff = self.kern.K(X)                                         # :268
+            var = np.transpose(Kff[None] + delta_cov)                    # :275-276  [P,P,D]
+            return mean + self.mean_function(X), var
         delta_cov = np.sum(A_tiled * B, 1)                               # :271
         Kff = self.kern.K_diag(X)                                        # :272
         var = (Kff[None] + delta_cov).T                                  # :275-276
         return mean + self.mean_function(X), var                         # :278
 
     # layers.py:63-85
-    def conditional_SND(self, X):
+    def conditional_SND(self, X, full_cov=False):
         S, N, D = X.shape
+        if full_cov:                                                     # :77-80: one conditional per sample
+            out = [self.conditional_ND(X[s], full_cov=True) for s in range(S)]
+            return np.stack([m for m, _ in out]), np.stack([v for _, v in out])       # [S,N,D], [S,N,N,D]
         mean, var = self.conditional_ND(X.reshape(S * N, D))
         return mean.reshape(S, N, self.num_outputs), var.reshape(S, N, self.num_outputs)
 
     # layers.py:87-130 (input_prop_dim unused by DGP)
-    def sample_from_conditional(self, X, z):
-        mean, var = self.conditional_SND(X)
+    def sample_from_conditional(self, X, z, full_cov=False):
+        mean, var = self.conditional_SND(X, full_cov=full_cov)
+        if full_cov:                                                     # utils.py:43-51
+            S, N, D = mean.shape
+            v = np.transpose(var, (0, 3, 1, 2)) + JITTER * np.eye(N)[None, None]      # SDNN
+            chol = np.linalg.cholesky(v)
+            f = np.transpose(mean, (0, 2, 1)) + (chol @ np.transpose(z, (0, 2, 1))[..., None])[..., 0]
+            return np.transpose(f, (0, 2, 1)), mean, var
         samples = mean + z * (var + JITTER) ** 0.5                       # utils.py:41
         return samples, mean, var
 
@@ -216,11 +230,11 @@ class OracleDGP:
         self.data = (np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64))
 
     # dgp.py:34-63
-    def propagate(self, X, S, zs):
+    def propagate(self, X, S, zs, full_cov=False):
         F = np.tile(X[None], [S, 1, 1])
         Fs, Fmeans, Fvars = [], [], []
         for layer, z in zip(self.layers, zs):
-            F, Fmean, Fvar = layer.sample_from_conditional(F, z)
+            F, Fmean, Fvar = layer.sample_from_conditional(F, z, full_cov=full_cov)
             Fs.append(F), Fmeans.append(Fmean), Fvars.append(Fvar)
         return Fs, Fmeans, Fvars
 

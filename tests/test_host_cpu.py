@@ -98,9 +98,9 @@ def test_only_the_accelerated_subset_is_accepted():
     X, Y, Z = notebook_data()
     with pytest.raises(Exception):
         DGP(X, Y, Z, [RBF(1.0, [1.0])] * 2, [1, 1], Gaussian())          # one kernel per layer is required
-    m = DGP(X, Y, Z, [RBF(1.0, [1.0]) for _ in range(3)], [1, 1], Gaussian())
-    with pytest.raises(NotImplementedError):
-        m.propagate(X, full_cov=True)
+    from dgp_dace.utils.layers import SVGP_Layer
+    with pytest.raises(NotImplementedError):                    # input propagation is unused by DGP and not offered
+        SVGP_Layer(RBF(1.0, [1.0]), Z, 1, None, input_prop_dim=1)
 
 
 def test_library_exports_every_symbol_declared_in_the_header():
