@@ -73,6 +73,13 @@ hipError_t rbf_kuf_bwd_finish(hipStream_t st, const double* GX, const double* x2
 // out[0] = sum_{i >= j} Lu[i][j] Q[i][j] = sum_p dk_p . k_p  (k = Lu c, Q = sum_p dk_p c_p^T): the variance gradient of
 // the Kuf path for kernels whose e factor differs from k
 hipError_t lower_dot(hipStream_t st, const double* Lu, const double* Q, int M, int Mp, double* out);
+// exact GP regression (gpflow GPR, SO_BO.py:187-200): pieces beyond the shared Kuu / Cholesky / GEMM machinery
+hipError_t add_diag(hipStream_t st, double* A, int M, int Mp, double v);
+hipError_t gpr_scalars(hipStream_t st, const double* A /* L^-1 Y [N x Dy] */, const double* L, const double* S, int N, int Np,
+                       int Dy, double* out /* [0] log marginal likelihood, [1] trace(S) */);
+hipError_t gpr_dk(hipStream_t st, double* S /* alpha alpha^T -> d lml / dK */, const double* Kinv, int Dy, int Np);
+hipError_t gpr_predict_var(hipStream_t st, const double* cnp, int nplane, long pstride, long N, int Dy, double kvar, double add,
+                           double* var);
 hipError_t wcat_transpose(hipStream_t st, const double* Wcat, int Mp, int D, double* WT);
 hipError_t sub_identity(hipStream_t st, double* S, int M, int Mp, int batch);
 hipError_t symmetrize_lower(hipStream_t st, double* G, int Mp, int batch);

@@ -582,4 +582,66 @@ hipError_t natgrad_mu(hipStream_t st, const double* Sn, const double* g_qmu_p, d
   LAUNCH_CHECK();
 }
 
+// ---------------------------------------------------------------------------------------- exact GP (gpflow GPR) pieces
+// A[i][i] += v for i < M
+__global__ void add_diag_kernel(double* __restrict__ A, int M, int Mp, double v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) A[(long)i * Mp + i] += v;
+}
+hipError_t add_diag(hipStream_t st, double* A, int M, int Mp, double v) {
+  hipLaunchKernelGGL(add_diag_kernel, dim3((M + 255) / 256), dim3(256), 0, st, A, M, Mp, v);
+  LAUNCH_CHECK();
+}
+// out[0] = -0.5 sum A^2 - Dy sum_i log L_ii - 0.5 N Dy log(2 pi);  out[1] = sum_i S_ii   (one block)
+__global__ __launch_bounds__(256) void gpr_scalars_kernel(const double* __restrict__ A, const double* __restrict__ L,
+                                                          const double* __restrict__ S, int N, int Np, int Dy,
+                                                          double* __restrict__ out) {
+  __shared__ double sh[8];
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int idx = threadIdx.x; idx < N * Dy; idx += blockDim.x) { const double v = A[idx]; a += v * v; }
+  for (int i = threadIdx.x; i < N; i += blockDim.x) { b += log(L[(long)i * Np + i]); c += S[(long)i * Np + i]; }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); c += __shfl_down(c, o); }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[w] = a; sh[4 + w] = b; }
+  __syncthreads();
+  double a2 = sh[0] + sh[1] + sh[2] + sh[3], b2 = sh[4] + sh[5] + sh[6] + sh[7];
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = -0.5 * a2 - Dy * b2 - 0.5 * N * Dy * 1.8378770664093454836;
+    out[1] = sh[0] + sh[1] + sh[2] + sh[3];
+  }
+}
+hipError_t gpr_scalars(hipStream_t st, const double* A, const double* L, const double* S, int N, int Np, int Dy, double* out) {
+  hipLaunchKernelGGL(gpr_scalars_kernel, dim3(1), dim3(256), 0, st, A, L, S, N, Np, Dy, out);
+  LAUNCH_CHECK();
+}
+// S = 0.5 (S - Dy * Kinv)     (S holds alpha alpha^T on entry)
+__global__ void gpr_dk_kernel(double* __restrict__ S, const double* __restrict__ Kinv, int Dy, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < total) S[idx] = 0.5 * (S[idx] - Dy * Kinv[idx]);
+}
+hipError_t gpr_dk(hipStream_t st, double* S, const double* Kinv, int Dy, int Np) {
+  const long n = (long)Np * Np;
+  hipLaunchKernelGGL(gpr_dk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, Kinv, Dy, n);
+  LAUNCH_CHECK();
+}
+// var[i][d] = kvar - cn[i] (+ noise), cn = sum of the row-norm partial planes
+__global__ void gpr_predict_var_kernel(const double* __restrict__ cnp, int nplane, long pstride, long N, int Dy, double kvar,
+                                       double add, double* __restrict__ var) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * Dy) return;
+  const long i = idx / Dy;
+  double cn = 0.0;
+  for (int q = 0; q < nplane; ++q) cn += cnp[(long)q * pstride + i];
+  var[idx] = kvar - cn + add;
+}
+hipError_t gpr_predict_var(hipStream_t st, const double* cnp, int nplane, long pstride, long N, int Dy, double kvar, double add,
+                           double* var) {
+  hipLaunchKernelGGL(gpr_predict_var_kernel, dim3((unsigned)((N * Dy + 255) / 256)), dim3(256), 0, st, cnp, nplane, pstride, N, Dy,
+                     kvar, add, var);
+  LAUNCH_CHECK();
+}
+
 }  // namespace dgp

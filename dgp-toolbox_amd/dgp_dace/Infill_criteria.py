@@ -12,8 +12,8 @@ search-space transform (``x = lw + (up-lw)/(1+exp(u))``, Infill_criteria.py:63).
 * differential evolution (``tfp.optimizer.differential_evolution_minimize``, Infill_criteria.py:65-67) is restated in
   NumPy with TFP's defaults (rand/1/bin, differential_weight 0.5, crossover_prob 0.9).
 
-The exact-GP branch (``model.name == 'gpr'``) belongs to the reference's ``num_layers == 0`` path, which this
-repository does not cover.
+The exact-GP branch (``model.name == 'gpr'``, ``dgp_dace.models.gpr.GPR``) is evaluated from ``predict_y`` as in the
+reference; its Adam branch is not offered (no input gradient for the exact GP on the device yet): use method='DE'.
 """
 import numpy as np
 from scipy.special import ndtr
@@ -62,10 +62,17 @@ class Infill_criteria(object):
         raise NotImplementedError("method not implemented")
 
     @staticmethod
-    def _check(model):
-        if getattr(model, "name", None) != 'dgp':
-            raise NotImplementedError("only model.name == 'dgp' is covered (the exact-GP branch is the reference's "
-                                      "num_layers == 0 path, DESIGN.md §9)")
+    def _check(model, gradient=False):
+        name = getattr(model, "name", None)
+        if name not in ('dgp', 'gpr'):
+            raise NotImplementedError("model.name must be 'dgp' or 'gpr'")
+        if gradient and name != 'dgp':
+            raise NotImplementedError("the Adam branch needs d prediction / dx: offered for model.name == 'dgp' only")
+
+    @staticmethod
+    def _gpr_moments(model, x):
+        mean, var = model.predict_y(x)                    # Infill_criteria.py:28-29
+        return _np(mean), _np(var)
 
     def loss(self, model, x, *args, **kw):          # the reference wraps run in a tf.function; nothing to trace here
         return self.run(model, x, *args, **kw)
@@ -85,6 +92,7 @@ class Infill_criteria(object):
             self.x_opt = to_x(u_best).reshape(self.d, 1)
             self.IC_optimized = self.run(model, self.x_opt.reshape(1, self.d), **run_kw)
         if method in ('Adam', 'DE+Adam'):
+            self._check(model, gradient=True)
             if init_adam is None:
                 init_adam = np.zeros(self.d) if self.x_opt is None else self.x_opt
             x0 = np.asarray(init_adam, dtype=np.float64).reshape(-1)
@@ -141,6 +149,8 @@ class EI(Infill_criteria):
         self._check(model)
         x = _np(x)
         y_min = np.asarray(self.y_min, dtype=np.float64)
+        if model.name == 'gpr':
+            return as_tensor(-_ei(y_min, *self._gpr_moments(model, x))[0])
         if analytic:
             Fm, Fv = (_np(a) for a in model.predict_f(x, S=num_samples))
             ei, _, _ = _ei(y_min, *_moments(Fm, Fv))
@@ -183,8 +193,11 @@ class WB2(Infill_criteria):
     def run(self, model, x):
         self._check(model)
         x = _np(x)
-        Fm, Fv = (_np(a) for a in model.predict_y(x, num_samples=self.num_samples))
-        mean, var = _moments(Fm, Fv)
+        if model.name == 'gpr':
+            mean, var = self._gpr_moments(model, x)
+        else:
+            Fm, Fv = (_np(a) for a in model.predict_y(x, num_samples=self.num_samples))
+            mean, var = _moments(Fm, Fv)
         ei, _, _ = _ei(np.asarray(self.y_min, dtype=np.float64), mean, var)
         return as_tensor(-(self._scale(x) * ei - mean))
 

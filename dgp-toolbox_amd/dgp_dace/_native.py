@@ -20,7 +20,7 @@ DGP_OK, ERR_INVALID, ERR_HIP, ERR_NOT_PD, ERR_NO_DEVICE, ERR_NONFINITE = 0, -1, 
 SYMBOLS = [
     "dgp_create", "dgp_destroy", "dgp_last_error", "dgp_sync", "dgp_device_info", "dgp_model_set", "dgp_param_count",
     "dgp_params_get", "dgp_params_set", "dgp_data_set", "dgp_set_workspace_limit", "dgp_elbo", "dgp_propagate",
-    "dgp_propagate_vjp", "dgp_propagate_full_cov",
+    "dgp_propagate_vjp", "dgp_propagate_full_cov", "dgp_gpr_lml", "dgp_gpr_predict",
     "dgp_grad_partial", "dgp_acc_info", "dgp_acc_bind", "dgp_grad_finish", "dgp_grad_get", "dgp_last_elbo",
     "dgp_adam_reset", "dgp_adam_step", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_dev_gemm",
     "dgp_dev_chol", "dgp_dev_trinv", "dgp_dev_normals", "dgp_dev_mfma_peak",
@@ -78,6 +78,8 @@ def load():
         "dgp_propagate": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dpp, _dpp, _dpp, i32]),
         "dgp_propagate_vjp": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dp, _dp, _dp, _dp]),
         "dgp_propagate_full_cov": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dpp, _dpp, _dpp]),
+        "dgp_gpr_lml": (C.c_int, [vp, i32, _dp, _dp, i64, i32, i32, C.c_double, _dp, C.c_double, _dp, _dp]),
+        "dgp_gpr_predict": (C.c_int, [vp, i32, _dp, _dp, i64, i32, i32, C.c_double, _dp, C.c_double, _dp, i64, i32, _dp, _dp]),
         "dgp_grad_partial": (C.c_int, [vp, i32, u64, _dpp]),
         "dgp_acc_info": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "dgp_acc_bind": (C.c_int, [vp, vp]),
@@ -215,6 +217,24 @@ class Context:
         self._chk(self._lib.dgp_propagate_full_cov(self._h, _ptr(Xnew), Nn, int(S), int(seed) & (2 ** 64 - 1), zp,
                                                    _ptr_array(Fs), _ptr_array(Fm), _ptr_array(Fv)))
         return Fs, Fm, Fv
+
+    # ---- exact GP regression (stateless calls) ---------------------------------------------------
+    def gpr_lml(self, kind, X, Y, variance, lengthscales, noise, want_grad=True):
+        X, Y, ls = _c(X), _c(Y), _c(lengthscales)
+        lml = C.c_double()
+        g = np.empty(2 + ls.size) if want_grad else None
+        self._chk(self._lib.dgp_gpr_lml(self._h, int(kind), _ptr(X), _ptr(Y), X.shape[0], X.shape[1], Y.shape[1],
+                                        float(variance), _ptr(ls), float(noise), C.byref(lml),
+                                        _ptr(g) if want_grad else None))
+        return lml.value, g
+
+    def gpr_predict(self, kind, X, Y, variance, lengthscales, noise, Xnew, add_noise):
+        X, Y, ls, Xnew = _c(X), _c(Y), _c(lengthscales), _c(Xnew)
+        mean, var = np.empty((Xnew.shape[0], Y.shape[1])), np.empty((Xnew.shape[0], Y.shape[1]))
+        self._chk(self._lib.dgp_gpr_predict(self._h, int(kind), _ptr(X), _ptr(Y), X.shape[0], X.shape[1], Y.shape[1],
+                                            float(variance), _ptr(ls), float(noise), _ptr(Xnew), Xnew.shape[0],
+                                            1 if add_noise else 0, _ptr(mean), _ptr(var)))
+        return mean, var
 
     def propagate_vjp(self, Xnew, S, seed=0, zs=None, f_bar=None, mean_bar=None, var_bar=None):
         """d(sum of cotangent * last-layer output)/dXnew, [Nn, D_in] (dgp_propagate_vjp)."""

@@ -101,6 +101,18 @@ int dgp_propagate_full_cov(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t
 int dgp_propagate_vjp(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
                       const double* f_bar, const double* mean_bar, const double* var_bar, double* xbar_out);
 
+/* ---- exact GP regression: replaces gpflow.models.GPR as SO_BO builds it for num_layers == 0 (SO_BO.py:187-200,
+ *      training :252-256, prediction through Infill_criteria.py:28-35).  Stateless (needs only dgp_create), N <= 1024.
+ *   dgp_gpr_lml     : log marginal likelihood  sum_d log N(Y_d | 0, K(X,X) + noise I)  and, if grad_out != NULL, its
+ *                     derivatives w.r.t. the constrained hyper-parameters: grad_out[0] variance, [1..D] lengthscales,
+ *                     [1+D] noise variance  (what tape.gradient(training_loss, trainable_variables) yields, negated)
+ *   dgp_gpr_predict : GPR.predict_f (add_noise == 0) / predict_y (add_noise != 0): mean_out, var_out host [Nn, Dy]  */
+int dgp_gpr_lml(dgp_ctx* ctx, int32_t kernel_kind, const double* X, const double* Y, int64_t N, int32_t D, int32_t Dy,
+                double variance, const double* lengthscales, double noise_variance, double* lml_out, double* grad_out);
+int dgp_gpr_predict(dgp_ctx* ctx, int32_t kernel_kind, const double* X, const double* Y, int64_t N, int32_t D, int32_t Dy,
+                    double variance, const double* lengthscales, double noise_variance, const double* Xnew, int64_t Nn,
+                    int32_t add_noise, double* mean_out, double* var_out);
+
 /* ---- backward + optimisers: replaces the tf.GradientTape / Adam / NaturalGradient loop bodies
  *      (dgp.py:270-276, 326-345).  Split so that a multi-GPU host can all-reduce between the stages:
  *   dgp_grad_partial : this rank's sums over its data points (ELBO data term + every point-sum the

@@ -612,3 +612,43 @@ def test_full_cov_propagation_matches_oracle(case):
     Dy = g["Y"].shape[1]
     assert mean.shape == (2, 5, Dy) and var.shape == (2, 5, 5, Dy)
     assert np.all(np.linalg.eigvalsh(np.asarray(var)[0, :, :, 0]) > -1e-9)
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32", "matern52"])
+def test_exact_gp_regression_matches_oracle(kind):
+    """gpflow.models.GPR as SO_BO builds it for num_layers == 0 (SO_BO.py:187-200): log marginal likelihood, its
+    hyper-parameter gradient, predict_f / predict_y, a few Adam iterations and EI on it."""
+    import gpr_oracle as G
+    from dgp_dace import Infill_criteria as IC
+    from dgp_dace.gpflow_compat import RBF, Matern32, Matern52
+    from dgp_dace.models.gpr import GPR
+    rng = np.random.default_rng(7)
+    N, D = 90, 3
+    X, Xs = rng.uniform(-1, 1, (N, D)), rng.uniform(-1, 1, (13, D))
+    Y = np.sin(X @ rng.standard_normal((D, 1))) + 0.05 * rng.standard_normal((N, 1))
+    ls, var, noise = np.array([0.7, 1.2, 0.9]), 1.3, 2e-2
+    pk = {"rbf": RBF, "matern32": Matern32, "matern52": Matern52}[kind]
+    ok = {"rbf": O.RBF, "matern32": O.Matern32, "matern52": O.Matern52}[kind](var, ls)
+    m = GPR((X, Y), pk(var, ls), noise_variance=noise)
+    assert m.name == "gpr"
+    want = G.log_marginal_likelihood(ok, X, Y, noise)
+    assert abs(m.log_marginal_likelihood() - want) < 1e-9 * abs(want)
+    assert abs(m.training_loss_closure()() + want) < 1e-9 * abs(want)
+    loss, g = m.loss_and_grad()
+    lml, gv, gl, gn = G.lml_and_grads(ok, X, Y, noise)
+    want_g = -np.concatenate([[gv], gl, [gn]])
+    _close(g, want_g, rtol=0, atol=1e-8 * np.abs(want_g).max())
+    mean, v = m.predict_y(Xs)
+    omean, ov = G.predict_y(ok, X, Y, noise, Xs)
+    _close(mean, omean, rtol=1e-8, atol=1e-10)
+    _close(v, ov, rtol=1e-7, atol=1e-10)
+    fm, fv = m.predict_f(Xs)
+    _close(fv, ov - noise, rtol=1e-7, atol=1e-10)
+    # EI on the exact GP (Infill_criteria.py:28-35)
+    c = IC.EI(float(Y.min()) + 0.2, D)
+    ei = IC._ei(float(Y.min()) + 0.2, omean, ov)[0]
+    _close(c.run(m, Xs), -ei, rtol=1e-7, atol=1e-10)
+    # Adam on the unconstrained hyper-parameters lowers the loss (tf.optimizers.Adam() defaults but a larger step)
+    l0 = m.training_loss()
+    l1 = m.optimize_adam(iterations=30, lr=0.02)
+    assert m.training_loss() < l0 and np.isfinite(l1)

@@ -223,10 +223,13 @@ def test_infill_host_math_without_a_device():
     u = IC._differential_evolution(f, np.zeros(2), 1.5, 40, 120, np.random.default_rng(1))
     np.testing.assert_allclose(u, [1.0, -2.0], atol=1e-3)
     assert all(c == (40, 2) for c in calls)
-    # only the DGP branch exists
+    # unknown model kinds are refused; the exact GP has no Adam branch
+    class Other: name = 'svgp'
+    with pytest.raises(NotImplementedError):
+        IC.EI(0.0, 2).run(Other(), np.zeros((1, 2)))
     class Gpr: name = 'gpr'
     with pytest.raises(NotImplementedError):
-        IC.EI(0.0, 2).run(Gpr(), np.zeros((1, 2)))
+        IC.EI(0.0, 2).optimize(Gpr(), (np.zeros(2), np.ones(2)), method='Adam')
 
 
 def test_bench_flop_accounting_matches_the_survey_tables():

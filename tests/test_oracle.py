@@ -147,3 +147,25 @@ def test_matern_torch_twin_matches_numpy_oracle():
         k = cls(1.2, ls)
         got = OT.rbf_K(torch.tensor(1.2, dtype=OT.DT), torch.tensor(ls), torch.tensor(Z), torch.tensor(X), kind=k.kind)
         np.testing.assert_allclose(got.numpy(), k.K(Z, X), rtol=1e-13)
+
+
+def test_gpr_restatement_against_scikit_learn():
+    """Independent pin of the exact-GP restatement (gpflow GPR as SO_BO.py:187-200 builds it)."""
+    import gpr_oracle as G
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF as SkRBF, ConstantKernel, Matern
+    rng = np.random.default_rng(3)
+    X, Y, Xs = rng.uniform(-1, 1, (25, 3)), rng.standard_normal((25, 1)), rng.uniform(-1, 1, (7, 3))
+    ls, var, noise = np.array([0.6, 1.1, 0.9]), 1.4, 3e-2
+    for ok, sk in ((O.RBF(var, ls), SkRBF(ls)), (O.Matern32(var, ls), Matern(ls, nu=1.5)), (O.Matern52(var, ls), Matern(ls, nu=2.5))):
+        gp = GaussianProcessRegressor(ConstantKernel(var, "fixed") * sk, alpha=noise, optimizer=None).fit(X, Y)
+        assert abs(G.log_marginal_likelihood(ok, X, Y, noise) - gp.log_marginal_likelihood_value_) < 1e-9
+        m, s = gp.predict(Xs, return_std=True)
+        mean, v = G.predict_y(ok, X, Y, noise, Xs)
+        np.testing.assert_allclose(mean[:, 0], np.ravel(m), rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(v[:, 0] - noise, s ** 2, rtol=1e-7, atol=1e-10)
+        lml, gv, gl, gn = G.lml_and_grads(ok, X, Y, noise)
+        assert abs(lml - G.log_marginal_likelihood(ok, X, Y, noise)) < 1e-10
+        h = 1e-6
+        fd = (G.log_marginal_likelihood(ok, X, Y, noise + h) - G.log_marginal_likelihood(ok, X, Y, noise - h)) / (2 * h)
+        assert abs(fd - gn) < 1e-5 * max(1.0, abs(fd))
