@@ -1306,6 +1306,49 @@ int dgp_gpr_predict(dgp_ctx* ctx, int32_t kernel_kind, const double* X, const do
   return check_flags(ctx);
 }
 
+int dgp_gpr_predict_vjp(dgp_ctx* ctx, int32_t kernel_kind, const double* X, const double* Y, int64_t N, int32_t D, int32_t Dy,
+                        double variance, const double* lengthscales, double noise_variance, const double* Xnew, int64_t Nn,
+                        const double* mean_bar, const double* var_bar, double* xbar_out) {
+  if (!ctx || !Xnew || Nn <= 0 || !mean_bar || !var_bar || !xbar_out) return DGP_ERR_INVALID;
+  GprFit f;
+  RET(gpr_fit(ctx, f, kernel_kind, X, Y, N, D, Dy, variance, lengthscales, noise_variance));
+  const int Np = f.Np, w1 = D + 1;
+  const long Pm = pad_rows(Nn);
+  double *Xn = nullptr, *Kt = nullptr, *Et = nullptr, *Ct = nullptr, *Cb = nullptr, *Kb = nullptr, *Gt = nullptr, *mb = nullptr,
+         *vb = nullptr, *Z1 = nullptr, *X1 = nullptr, *R1 = nullptr, *xb = nullptr;
+  struct Free { std::vector<double**> ps; ~Free() { for (auto p : ps) dev_free(*p); } } guard;
+  auto get = [&](double** p, long n) -> int { guard.ps.push_back(p); return dev_alloc(ctx, p, (size_t)n); };
+  RET(get(&Xn, Nn * D)); RET(get(&Kt, Pm * Np)); RET(get(&Ct, Pm * Np)); RET(get(&Cb, Pm * Np)); RET(get(&Kb, Pm * Np));
+  RET(get(&Gt, Pm * Np)); RET(get(&mb, Pm * Dy)); RET(get(&vb, Pm * Dy)); RET(get(&Z1, (long)Np * w1)); RET(get(&X1, Pm * w1));
+  RET(get(&R1, Pm * w1)); RET(get(&xb, Nn * D));
+  if (kernel_kind != DGP_KERNEL_RBF) RET(get(&Et, Pm * Np));
+  HIPCHK(hipMemcpyAsync(Xn, Xnew, (size_t)Nn * D * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemsetAsync(mb, 0, (size_t)Pm * Dy * 8, ctx->st));
+  HIPCHK(hipMemsetAsync(vb, 0, (size_t)Pm * Dy * 8, ctx->st));
+  HIPCHK(hipMemcpyAsync(mb, mean_bar, (size_t)Nn * Dy * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(vb, var_bar, (size_t)Nn * Dy * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemsetAsync(Kt, 0, (size_t)Pm * Np * 8, ctx->st));
+  if (Et) HIPCHK(hipMemsetAsync(Et, 0, (size_t)Pm * Np * 8, ctx->st));
+  HIPCHK(rbf_kuf(ctx->st, kernel_kind, Xn, Nn, 0, f.Xd, f.pd, f.pd + 1, (int)N, Np, D, Kt, Et));
+  {
+    GemmArgs a = mk(Pm, Np, Np, Kt, Np, f.Linv, Np, Ct, Np);
+    a.tri = TRI_B_UPPER; a.triblk = Np;
+    RET(GX(ctx, 0, GEMM_NT, a));
+  }
+  HIPCHK(gpr_cbar(ctx->st, mb, vb, f.A, Ct, Pm, Np, Dy, Cb));
+  {  // dK = dC L^-1, g = dK .* e  (the RBF backward of an SVGP layer, with the training inputs as inducing inputs)
+    GemmArgs a = mk(Pm, Np, Np, Cb, Np, f.Linv, Np, Kb, Np);
+    a.tri = TRI_B_LOWER; a.triblk = Np; a.emul = Et ? Et : Kt; a.C2 = Gt;
+    RET(GX(ctx, 0, GEMM_NN, a));
+  }
+  HIPCHK(make_z1(ctx->st, f.Xd, (int)N, Np, D, Z1));
+  HIPCHK(make_x1(ctx->st, Xn, 0, Nn, D, X1));
+  RET(GX(ctx, 0, GEMM_NN, mk(Pm, w1, Np, Gt, Np, Z1, w1, R1, w1)));
+  HIPCHK(xbar_finish(ctx->st, R1, X1, Nn, f.pd + 1, D, Dy, 0, nullptr, mb, 1, xb, nullptr));
+  HIPCHK(hipMemcpyAsync(xbar_out, xb, (size_t)Nn * D * 8, hipMemcpyDeviceToHost, ctx->st));
+  return check_flags(ctx);
+}
+
 // ----------------------------------------------------------------------------------- unit-level hooks
 int dgp_dev_gemm(dgp_ctx* ctx, int32_t op, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B,
                  int64_t ldb, double* C, int64_t ldc, double alpha, int32_t beta, int32_t splits, int32_t tri,

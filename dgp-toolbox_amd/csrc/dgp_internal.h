@@ -78,6 +78,8 @@ hipError_t add_diag(hipStream_t st, double* A, int M, int Mp, double v);
 hipError_t gpr_scalars(hipStream_t st, const double* A /* L^-1 Y [N x Dy] */, const double* L, const double* S, int N, int Np,
                        int Dy, double* out /* [0] log marginal likelihood, [1] trace(S) */);
 hipError_t gpr_dk(hipStream_t st, double* S /* alpha alpha^T -> d lml / dK */, const double* Kinv, int Dy, int Np);
+hipError_t gpr_cbar(hipStream_t st, const double* mbar, const double* vbar, const double* A, const double* Ct, long P, int Np,
+                    int Dy, double* Cbar);
 hipError_t gpr_predict_var(hipStream_t st, const double* cnp, int nplane, long pstride, long N, int Dy, double kvar, double add,
                            double* var);
 hipError_t wcat_transpose(hipStream_t st, const double* Wcat, int Mp, int D, double* WT);

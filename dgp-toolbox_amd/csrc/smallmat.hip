@@ -644,4 +644,23 @@ hipError_t gpr_predict_var(hipStream_t st, const double* cnp, int nplane, long p
   LAUNCH_CHECK();
 }
 
+// dC[p][i] = sum_d mbar[p][d] A[i][d] - 2 (sum_d vbar[p][d]) C[p][i]: cotangent of c = L^-1 k(X, x_p) for the exact GP,
+// where mean = c^T A and var = kdiag - |c|^2
+__global__ void gpr_cbar_kernel(const double* __restrict__ mbar, const double* __restrict__ vbar, const double* __restrict__ A,
+                                const double* __restrict__ Ct, long P, int Np, int Dy, double* __restrict__ Cbar) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * Np) return;
+  const long p = idx / Np;
+  const int i = (int)(idx % Np);
+  double a = 0.0, sv = 0.0;
+  for (int d = 0; d < Dy; ++d) { a += mbar[p * Dy + d] * A[(long)i * Dy + d]; sv += vbar[p * Dy + d]; }
+  Cbar[idx] = a - 2.0 * sv * Ct[idx];
+}
+hipError_t gpr_cbar(hipStream_t st, const double* mbar, const double* vbar, const double* A, const double* Ct, long P, int Np,
+                    int Dy, double* Cbar) {
+  const long n = P * Np;
+  hipLaunchKernelGGL(gpr_cbar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mbar, vbar, A, Ct, P, Np, Dy, Cbar);
+  LAUNCH_CHECK();
+}
+
 }  // namespace dgp

@@ -13,7 +13,7 @@ search-space transform (``x = lw + (up-lw)/(1+exp(u))``, Infill_criteria.py:63).
   NumPy with TFP's defaults (rand/1/bin, differential_weight 0.5, crossover_prob 0.9).
 
 The exact-GP branch (``model.name == 'gpr'``, ``dgp_dace.models.gpr.GPR``) is evaluated from ``predict_y`` as in the
-reference; its Adam branch is not offered (no input gradient for the exact GP on the device yet): use method='DE'.
+reference; its Adam branch takes the input gradient from ``GPR.predict_vjp``.
 """
 import numpy as np
 from scipy.special import ndtr
@@ -66,8 +66,8 @@ class Infill_criteria(object):
         name = getattr(model, "name", None)
         if name not in ('dgp', 'gpr'):
             raise NotImplementedError("model.name must be 'dgp' or 'gpr'")
-        if gradient and name != 'dgp':
-            raise NotImplementedError("the Adam branch needs d prediction / dx: offered for model.name == 'dgp' only")
+        if gradient and name == 'gpr' and not hasattr(model, "predict_vjp"):
+            raise NotImplementedError("the Adam branch needs d prediction / dx (dgp_dace.models.gpr.GPR.predict_vjp)")
 
     @staticmethod
     def _gpr_moments(model, x):
@@ -162,6 +162,9 @@ class EI(Infill_criteria):
 
     def _value_and_grad(self, model, x, analytic=True, num_samples=1000):
         y_min = np.asarray(self.y_min, dtype=np.float64)
+        if model.name == 'gpr':
+            ei, d_mean, d_var = _ei(y_min, *self._gpr_moments(model, x))
+            return -ei, _np(model.predict_vjp(x, -d_mean, -d_var))
         if analytic:
             Fm, Fv = (_np(a) for a in model.predict_f(x, S=num_samples))
             mean, var = _moments(Fm, Fv)
@@ -202,14 +205,21 @@ class WB2(Infill_criteria):
         return as_tensor(-(self._scale(x) * ei - mean))
 
     def _value_and_grad(self, model, x):
-        Fm, Fv = (_np(a) for a in model.predict_y(x, num_samples=self.num_samples))
-        mean, var = _moments(Fm, Fv)
+        gpr = model.name == 'gpr'
+        if gpr:
+            mean, var = self._gpr_moments(model, x)
+        else:
+            Fm, Fv = (_np(a) for a in model.predict_y(x, num_samples=self.num_samples))
+            mean, var = _moments(Fm, Fv)
         ei, d_mean, d_var = _ei(np.asarray(self.y_min, dtype=np.float64), mean, var)
         s = self._scale(x)
         s_col = s if np.ndim(s) == 0 else s.sum(1, keepdims=True)      # WB2S broadcasts [N,d] * [N,1]: sum over d
         k = 1.0 if np.ndim(s) == 0 else float(x.shape[1])              # ... and "- mean" is then counted d times
-        mean_bar, var_bar = _moment_cotangents(Fm, mean, -(s_col * d_mean) + k, -(s_col * d_var))
-        gx = _np(model.propagate_vjp(x, S=self.num_samples, mean_bar=mean_bar, var_bar=var_bar))
+        if gpr:
+            gx = _np(model.predict_vjp(x, -(s_col * d_mean) + k, -(s_col * d_var)))
+        else:
+            mean_bar, var_bar = _moment_cotangents(Fm, mean, -(s_col * d_mean) + k, -(s_col * d_var))
+            gx = _np(model.propagate_vjp(x, S=self.num_samples, mean_bar=mean_bar, var_bar=var_bar))
         if np.ndim(s) != 0:
             gx = gx - self._dscale(x) * ei                              # explicit dependence of the scale on x
         return -(s * ei - mean), gx

@@ -20,7 +20,7 @@ DGP_OK, ERR_INVALID, ERR_HIP, ERR_NOT_PD, ERR_NO_DEVICE, ERR_NONFINITE = 0, -1, 
 SYMBOLS = [
     "dgp_create", "dgp_destroy", "dgp_last_error", "dgp_sync", "dgp_device_info", "dgp_model_set", "dgp_param_count",
     "dgp_params_get", "dgp_params_set", "dgp_data_set", "dgp_set_workspace_limit", "dgp_elbo", "dgp_propagate",
-    "dgp_propagate_vjp", "dgp_propagate_full_cov", "dgp_gpr_lml", "dgp_gpr_predict",
+    "dgp_propagate_vjp", "dgp_propagate_full_cov", "dgp_gpr_lml", "dgp_gpr_predict", "dgp_gpr_predict_vjp",
     "dgp_grad_partial", "dgp_acc_info", "dgp_acc_bind", "dgp_grad_finish", "dgp_grad_get", "dgp_last_elbo",
     "dgp_adam_reset", "dgp_adam_step", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_dev_gemm",
     "dgp_dev_chol", "dgp_dev_trinv", "dgp_dev_normals", "dgp_dev_mfma_peak",
@@ -80,6 +80,7 @@ def load():
         "dgp_propagate_full_cov": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dpp, _dpp, _dpp]),
         "dgp_gpr_lml": (C.c_int, [vp, i32, _dp, _dp, i64, i32, i32, C.c_double, _dp, C.c_double, _dp, _dp]),
         "dgp_gpr_predict": (C.c_int, [vp, i32, _dp, _dp, i64, i32, i32, C.c_double, _dp, C.c_double, _dp, i64, i32, _dp, _dp]),
+        "dgp_gpr_predict_vjp": (C.c_int, [vp, i32, _dp, _dp, i64, i32, i32, C.c_double, _dp, C.c_double, _dp, i64, _dp, _dp, _dp]),
         "dgp_grad_partial": (C.c_int, [vp, i32, u64, _dpp]),
         "dgp_acc_info": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "dgp_acc_bind": (C.c_int, [vp, vp]),
@@ -235,6 +236,16 @@ class Context:
                                             float(variance), _ptr(ls), float(noise), _ptr(Xnew), Xnew.shape[0],
                                             1 if add_noise else 0, _ptr(mean), _ptr(var)))
         return mean, var
+
+    def gpr_predict_vjp(self, kind, X, Y, variance, lengthscales, noise, Xnew, mean_bar, var_bar):
+        X, Y, ls, Xnew, mb, vb = _c(X), _c(Y), _c(lengthscales), _c(Xnew), _c(mean_bar), _c(var_bar)
+        if mb.shape != (Xnew.shape[0], Y.shape[1]) or vb.shape != mb.shape:
+            raise ValueError("cotangents must be [Nn, Dy]")
+        out = np.empty(Xnew.shape)
+        self._chk(self._lib.dgp_gpr_predict_vjp(self._h, int(kind), _ptr(X), _ptr(Y), X.shape[0], X.shape[1], Y.shape[1],
+                                                float(variance), _ptr(ls), float(noise), _ptr(Xnew), Xnew.shape[0],
+                                                _ptr(mb), _ptr(vb), _ptr(out)))
+        return out
 
     def propagate_vjp(self, Xnew, S, seed=0, zs=None, f_bar=None, mean_bar=None, var_bar=None):
         """d(sum of cotangent * last-layer output)/dXnew, [Nn, D_in] (dgp_propagate_vjp)."""

@@ -80,6 +80,13 @@ class GPR:
         mean, var = self._engine().gpr_predict(kind, *self.data, v, ls, s2, Xnew, add_noise=True)
         return as_tensor(mean), as_tensor(var)
 
+    def predict_vjp(self, Xnew, mean_bar, var_bar):
+        """d( sum(mean_bar*mean) + sum(var_bar*var) ) / dXnew of predict_y / predict_f (the noise is constant in x):
+        what `tape.gradient` gives the Adam branch of the acquisition optimisers (Infill_criteria.py:69-85)."""
+        kind, v, ls, s2 = self._hyper()
+        Xnew = np.asarray(Xnew.numpy() if hasattr(Xnew, "numpy") else Xnew, dtype=np.float64)
+        return as_tensor(self._engine().gpr_predict_vjp(kind, *self.data, v, ls, s2, Xnew, mean_bar, var_bar))
+
     # ------------------------------------------------------------------ training (SO_BO.py:252-256)
     def loss_and_grad(self):
         """training_loss and its gradient w.r.t. the constrained (variance, lengthscales[D], noise variance)."""

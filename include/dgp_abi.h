@@ -112,6 +112,12 @@ int dgp_gpr_lml(dgp_ctx* ctx, int32_t kernel_kind, const double* X, const double
 int dgp_gpr_predict(dgp_ctx* ctx, int32_t kernel_kind, const double* X, const double* Y, int64_t N, int32_t D, int32_t Dy,
                     double variance, const double* lengthscales, double noise_variance, const double* Xnew, int64_t Nn,
                     int32_t add_noise, double* mean_out, double* var_out);
+/* d( sum(mean_bar * mean) + sum(var_bar * var) ) / dXnew for the same prediction: what tape.gradient yields in the Adam
+ * branch of the acquisition optimisers on a 'gpr' model (Infill_criteria.py:69-85); mean_bar, var_bar host [Nn, Dy],
+ * xbar_out host [Nn, D]                                                                                           */
+int dgp_gpr_predict_vjp(dgp_ctx* ctx, int32_t kernel_kind, const double* X, const double* Y, int64_t N, int32_t D, int32_t Dy,
+                        double variance, const double* lengthscales, double noise_variance, const double* Xnew, int64_t Nn,
+                        const double* mean_bar, const double* var_bar, double* xbar_out);
 
 /* ---- backward + optimisers: replaces the tf.GradientTape / Adam / NaturalGradient loop bodies
  *      (dgp.py:270-276, 326-345).  Split so that a multi-GPU host can all-reduce between the stages:

@@ -648,6 +648,21 @@ def test_exact_gp_regression_matches_oracle(kind):
     c = IC.EI(float(Y.min()) + 0.2, D)
     ei = IC._ei(float(Y.min()) + 0.2, omean, ov)[0]
     _close(c.run(m, Xs), -ei, rtol=1e-7, atol=1e-10)
+    # input gradient of the prediction and of the criteria (Adam branch of Infill_criteria.py:69-85)
+    a, b = rng.standard_normal(omean.shape), rng.standard_normal(omean.shape)
+    gx = np.asarray(m.predict_vjp(Xs, a, b))
+    dirn, h = rng.standard_normal(Xs.shape), 1e-6
+    f = [float((a * mm).sum() + (b * vv).sum()) for mm, vv in (G.predict_y(ok, X, Y, noise, Xs + sg * h * dirn) for sg in (1, -1))]
+    fd = (f[0] - f[1]) / (2 * h)
+    assert abs(fd - float((gx * dirn).sum())) < 1e-6 * max(1.0, abs(fd))
+    for crit in (IC.EI(float(Y.min()) + 0.2, D), IC.WB2(float(Y.min()) + 0.2, D)):
+        val, gxc = crit._value_and_grad(m, Xs)
+        f = [float(np.asarray(crit.run(m, Xs + sg * 1e-5 * dirn)).sum()) for sg in (1, -1)]
+        fd = (f[0] - f[1]) / 2e-5
+        assert abs(fd - float((gxc * dirn).sum())) < 1e-5 * max(1.0, abs(fd))
+    x_opt = IC.EI(float(Y.min()) + 0.2, D).optimize(m, (X.min(0), X.max(0)), popsize_DE=16, iterations_DE=5, iterations_adam=5,
+                                                    method='DE+Adam', seed=1)
+    assert x_opt.shape == (D, 1)
     # Adam on the unconstrained hyper-parameters lowers the loss (tf.optimizers.Adam() defaults but a larger step)
     l0 = m.training_loss()
     l1 = m.optimize_adam(iterations=30, lr=0.02)

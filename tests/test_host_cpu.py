@@ -223,7 +223,7 @@ def test_infill_host_math_without_a_device():
     u = IC._differential_evolution(f, np.zeros(2), 1.5, 40, 120, np.random.default_rng(1))
     np.testing.assert_allclose(u, [1.0, -2.0], atol=1e-3)
     assert all(c == (40, 2) for c in calls)
-    # unknown model kinds are refused; the exact GP has no Adam branch
+    # unknown model kinds are refused; an exact GP without an input gradient has no Adam branch
     class Other: name = 'svgp'
     with pytest.raises(NotImplementedError):
         IC.EI(0.0, 2).run(Other(), np.zeros((1, 2)))
