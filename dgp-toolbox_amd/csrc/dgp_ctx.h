@@ -1,0 +1,610 @@
+// Internal to libdgp_hip.so: the context, the per-layer state and the orchestration helpers shared by the
+// translation units that implement include/dgp_abi.h (dgp_abi.hip, dgp_gpr.hip).  Everything here has internal
+// linkage (anonymous namespace): each unit compiles its own copy of what it uses.
+#pragma once
+// libdgp_hip.so: context, orchestration of the SVGP-layer ELBO path and the C-ABI (include/dgp_abi.h).
+//
+// Reference path being replaced (all executed by TensorFlow/GPflow there):
+//   DGP_Base.propagate / ELBO            dgp_dace/models/dgp.py:34-109
+//   SVGP_Layer.conditional_ND / KL        dgp_dace/utils/layers.py:227-308
+//   Layer.sample_from_conditional         dgp_dace/utils/layers.py:87-130, utils.py:22-51
+//   DGP.optimize_adam / optimize_nat_adam dgp_dace/models/dgp.py:255-345 (loop bodies)
+//
+// Whitened formulation used on the device (identical in exact arithmetic to layers.py:243-276):
+//   Lu = chol(K(Z,Z) + 1e-6 I),  c_p = Lu^-1 k(Z, x_p),  W_d = Lu^-1 L_q,d (non-white) or L_q,d (white),
+//   u = Lu^-1 q_mu (non-white) or q_mu,   mean = c^T u + mf(x),   var = k_diag - |c|^2 + |W_d^T c|^2.
+// Data layout in HBM: every per-point intermediate is point-major ([points][M] / [points][D][M]), so
+// a tile of points is one contiguous slab; a chunk of data points (all S samples of each point) goes
+// through forward-all-layers then backward-all-layers with its intermediates resident in HBM.
+#include "../../include/dgp_abi.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dgp_internal.h"
+
+using namespace dgp;
+
+namespace {
+
+struct Layer {
+  dgp_layer_desc d;
+  int Mp;
+  long off_Z, off_var, off_ls, off_qmu, off_qsqrt;   // offsets in the flat parameter vector
+  double *meanW = nullptr, *meanb = nullptr;
+  double *Kuu, *Lu, *Linv, *Lq, *qmu_p, *Wcat, *u;   // derived small matrices (padded to Mp)
+  double *Scat;                                      // [D*Mp x Mp] (backward only): W_d^T stacked when t_d is kept from the
+                                                     // forward pass (ctx->store_t), else S'_d = W_d W_d^T - I stacked
+  double *Tt = nullptr;                              // [points][D*Mp]: t_d = W_d^T c (training chunks, ctx->store_t)
+  double *Et = nullptr;                              // [points][Mp]: -2 dk/d(r2) of Kuf (training chunks, Matern kernels)
+  double *Euu = nullptr;                             // [Mp x Mp]: the same for Kuu (Matern kernels)
+  double *kdot = nullptr;                            // device scalar: sum_p dk_p . k_p (Matern kernels)
+  double *Z1;                                        // [Mp x (D_in+1)] = [Z | 1]
+  double *dLq, *dqmu_p;                              // d ELBO / d (Lq, q_mu) of the last grad_finish
+  long acc_Q, acc_G, acc_du, acc_GX, acc_x2, acc_dvar;
+  double *Kt, *Ct, *cnp, *tnp, *mean0, *mean, *var, *F, *mbar, *vbar;   // chunk workspace
+};
+
+constexpr int kNCat = 4;
+struct Prof {
+  bool on = false;
+  int depth = 0;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> cat;
+  size_t used = 0;
+  double ms[kNCat] = {0, 0, 0, 0}, flops[kNCat] = {0, 0, 0, 0}, bytes[kNCat] = {0, 0, 0, 0};
+  long launches[kNCat] = {0, 0, 0, 0};
+};
+
+}  // namespace
+
+struct dgp_ctx {
+  int device = 0;
+  int cu_count = 0;
+  hipStream_t st = nullptr;
+  bool own_stream = false;
+  std::string err;
+  std::vector<Layer> L;
+  long n_params = 0;
+  double *params = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  long adam_t = 0;
+  std::vector<ParamSeg> segs;
+  ParamSeg* segs_dev = nullptr;
+  double *mean_params = nullptr;
+  double *X = nullptr, *Y = nullptr;
+  long N = 0;
+  int D = 0, Dy = 0;
+  long n_goff = 0;
+  double *acc = nullptr, *acc_own = nullptr;
+  long n_acc = 0;
+  double* scal = nullptr;   // device scalars: [0] sum KL, [1] ELBO of last grad_finish, [2] scratch data term
+  int* info = nullptr;
+  char* ws = nullptr;
+  size_t ws_cap = 0;
+  long ws_limit = 96L << 30;
+  double *Cbar = nullptr, *Kbar = nullptr, *xbar = nullptr, *Gt = nullptr, *X1 = nullptr, *R1 = nullptr;
+  // small-matrix scratch, one set per side stream: the per-layer chains (prep, gradient finish, natural-gradient
+  // step) are independent of each other and run concurrently, one layer per side stream (LayerFork below)
+  static constexpr int kSide = 3;
+  double* smset[kSide][10] = {{nullptr}};
+  double** sm = smset[0];
+  hipStream_t side[kSide] = {nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr};
+  bool use_side = true;
+  // Option (DGP_STORE_T=1): keep t_d = W_d^T c from the forward pass (16 KB/point/layer at D=8, M=256), so that dC
+  // needs only the triangular products W_d t_d instead of the dense S'_d c.  Measured at config 2: the dC product
+  // 19.2 -> 15.7 ms (it now streams 16 GB, re-read per column tile), the T-product 12.0 -> 15.1 ms (the 16 GB store):
+  // no net gain, +32 GB of HBM traffic per iteration -> off by default.
+  bool store_t = false;
+  std::vector<double*> zs_dev;
+  std::vector<size_t> zs_cap;
+  double* Xnew = nullptr;
+  size_t Xnew_cap = 0;
+  std::vector<double*> out_dev[3];
+  std::vector<size_t> out_cap[3];
+  bool grad_ready = false;
+  bool segs_uploaded = false;
+  Prof prof;
+};
+
+namespace {
+
+int fail(dgp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[512];
+  if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  else snprintf(buf, sizeof buf, "%s", what);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define HIPCHK(x)                                                   \
+  do {                                                              \
+    hipError_t e_ = (x);                                            \
+    if (e_ != hipSuccess) return fail(ctx, DGP_ERR_HIP, #x, e_);    \
+  } while (0)
+#define RET(x)                  \
+  do {                          \
+    int r_ = (x);               \
+    if (r_ != DGP_OK) return r_; \
+  } while (0)
+
+inline long round_up(long x, long m) { return ((x + m - 1) / m) * m; }
+
+// ------------------------------------------------------------------------------- profiling helpers
+int prof_drain(dgp_ctx* ctx) {
+  Prof& p = ctx->prof;
+  if (p.used == 0) return DGP_OK;
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  for (size_t i = 0; i < p.used; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
+    p.ms[p.cat[i]] += ms;
+  }
+  p.used = 0;
+  return DGP_OK;
+}
+
+struct ProfScope {
+  dgp_ctx* ctx;
+  bool active;
+  size_t slot;
+  ProfScope(dgp_ctx* c, int cat, double flops, double bytes) : ctx(c), active(false), slot(0) {
+    Prof& p = c->prof;
+    if (!p.on) return;
+    p.flops[cat] += flops;
+    p.bytes[cat] += bytes;
+    if (p.depth++ > 0) return;          // nested scopes are covered by the outermost one
+    active = true;
+    if (p.used * 2 + 2 > p.ev.size()) {
+      if (p.ev.size() < 2 * 8192) {
+        const size_t old = p.ev.size();
+        p.ev.resize(old + 1024);
+        for (size_t i = old; i < p.ev.size(); ++i) (void)hipEventCreate(&p.ev[i]);
+        p.cat.resize(p.ev.size() / 2);
+      } else {
+        prof_drain(c);
+      }
+    }
+    slot = p.used++;
+    p.cat[slot] = cat;
+    p.launches[cat] += 1;
+    (void)hipEventRecord(p.ev[2 * slot], c->st);
+  }
+  ~ProfScope() {
+    Prof& p = ctx->prof;
+    if (!p.on) return;
+    if (active) (void)hipEventRecord(p.ev[2 * slot + 1], ctx->st);
+    if (p.depth > 0) --p.depth;
+  }
+};
+
+// ------------------------------------------------------------------------------- GEMM wrapper
+int G(dgp_ctx* ctx, int cat, GemmOp op, long M, long N, long K, const double* A, long lda, const double* B, long ldb,
+      double* C, long ldc, double alpha, int beta, int batch = 1, long sA = 0, long sB = 0, long sC = 0,
+      int splits = 1, int tri = TRI_NONE, long triblk = 0, double flops = 0.0, double bytes = 0.0) {
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.M = M; a.N = N; a.K = K;
+  a.sA = sA; a.sB = sB; a.sC = sC;
+  a.batch = batch; a.splits = splits; a.ksplit = 0;
+  a.alpha = alpha; a.beta = beta; a.tri = tri; a.triblk = triblk;
+  if (M <= 0 || N <= 0 || K <= 0) return DGP_OK;
+  ProfScope ps(ctx, cat, flops, bytes);
+  HIPCHK(gemm_f64(ctx->st, op, a));
+  return DGP_OK;
+}
+
+int GX(dgp_ctx* ctx, int cat, GemmOp op, GemmArgs a, double flops = 0.0, double bytes = 0.0) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return DGP_OK;
+  ProfScope ps(ctx, cat, flops, bytes);
+  HIPCHK(gemm_f64(ctx->st, op, a));
+  return DGP_OK;
+}
+
+GemmArgs mk(long M, long N, long K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
+            double alpha = 1.0, int beta = 0) {
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  a.sA = a.sB = a.sC = 0; a.batch = 1; a.splits = 1; a.ksplit = 0; a.alpha = alpha; a.beta = beta;
+  a.tri = TRI_NONE; a.triblk = 0;
+  return a;
+}
+
+// Runs independent per-layer chains of small kernels concurrently on three workers: the context's own stream and
+// two side streams (the runtime gives this process few hardware queues: with three side streams two of them shared
+// one, and raising GPU_MAX_HW_QUEUES slowed every launch).  Item i goes to worker i % 3 with that worker's scratch
+// set; the destructor joins everything back into the context's stream (also on error returns).
+struct LayerFork {
+  dgp_ctx* ctx;
+  hipStream_t main;
+  bool on;
+  ProfScope ps;
+  int used = 0;
+  LayerFork(dgp_ctx* c, int n_items) : ctx(c), main(c->st), on(c->use_side && n_items > 1), ps(c, 2, 0, 0) {
+    if (!on) return;
+    used = n_items - 1 < dgp_ctx::kSide - 1 ? n_items - 1 : dgp_ctx::kSide - 1;     // side streams in use
+    (void)hipEventRecord(c->ev_fork, main);
+    for (int i = 0; i < used; ++i) (void)hipStreamWaitEvent(c->side[i], c->ev_fork, 0);
+  }
+  void use(int i) {
+    if (!on) return;
+    const int w = i % dgp_ctx::kSide;
+    ctx->st = w == 0 ? main : ctx->side[w - 1];
+    ctx->sm = ctx->smset[w];
+  }
+  ~LayerFork() {
+    if (!on) return;
+    ctx->st = main;
+    ctx->sm = ctx->smset[0];
+    for (int i = 0; i < used; ++i) {
+      (void)hipEventRecord(ctx->ev_join[i], ctx->side[i]);
+      (void)hipStreamWaitEvent(main, ctx->ev_join[i], 0);
+    }
+  }
+};
+
+// Split-K factor for the reductions over points: all active workgroups of such a launch run equally long, so
+// their number should fill whole rounds of the resident slots (2 workgroups per CU); `active_tiles` counts the
+// output tiles that survive the triangular skip, times the batch.
+int pick_splits_tiles(dgp_ctx* ctx, long active_tiles, long K, long row_bytes = 0, long min_rows = 2048) {
+  // Chunk of points per split sized so that the streamed rows of one chunk (row_bytes each) stay in one XCD's
+  // 4 MiB L2 while all members of the chunk read them (see gemm_f64.h: XCD-grouped split-K mapping); the number
+  // of splits is a multiple of 8 (one group per XCD at a time).
+  // The members advance through their chunk in step, so L2 only has to hold the window between the fastest and
+  // the slowest member, not the whole chunk: a chunk of a few MiB keeps the hit rate while bounding the atomics.
+  if (row_bytes <= 0) row_bytes = 2048;
+  static long chunk_bytes = 0;
+  if (chunk_bytes == 0) {
+    const char* e = getenv("DGP_GRAM_CHUNK_BYTES");
+    chunk_bytes = e ? atol(e) : (8L << 20);
+    if (chunk_bytes < (1L << 16)) chunk_bytes = 1L << 16;
+  }
+  long chunk = chunk_bytes / row_bytes;
+  chunk = (chunk / 16) * 16;
+  if (chunk < 256) chunk = 256;
+  long s = (K + chunk - 1) / chunk;
+  // a launch of few members (skinny outputs, small shards of a multi-GPU run) still has to fill the chip: enough
+  // splits for ~2 workgroups per CU, as long as a split keeps >= min_rows of K (the atomics of a split cost a
+  // full tile of traffic: 2048 rows for 128x64 tiles, 256 for the skinny 128x16 ones)
+  const long fill = (2L * (ctx->cu_count > 0 ? ctx->cu_count : 256) + active_tiles - 1) / (active_tiles > 0 ? active_tiles : 1);
+  const long cap = K / min_rows;
+  if (s < fill) s = fill < cap ? fill : cap;
+  s = ((s + 7) / 8) * 8;
+  if (s * 16 > K) s = 1;                               // tiny reductions: no split
+  if (s > 32760) s = 32760;
+  return (int)s;
+}
+
+// number of 128x64 output tiles of an [Mp x Mp] lower-triangular target that are not skipped
+long lower_tiles(long Mp) {
+  long n = 0;
+  for (long m0 = 0; m0 < Mp; m0 += 128)
+    for (long n0 = 0; n0 < Mp; n0 += 64)
+      if (m0 + 127 >= n0) ++n;
+  return n;
+}
+
+int pick_splits(dgp_ctx* ctx, long Mrows, long Ncols, long K) {
+  const long tiles = ((Mrows + 127) / 128) * ((Ncols + 63) / 64);
+  return pick_splits_tiles(ctx, tiles, K, Mrows * 8, Ncols <= 16 ? 256 : 2048);
+}
+
+// ------------------------------------------------------------------------------- memory helpers
+template <typename T>
+int dev_alloc(dgp_ctx* ctx, T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  return DGP_OK;
+}
+template <typename T>
+void dev_free(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+int grow(dgp_ctx* ctx, double** p, size_t* cap, size_t n) {
+  if (*cap >= n && *p) return DGP_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  RET(dev_alloc(ctx, p, n));
+  *cap = n;
+  return DGP_OK;
+}
+
+void free_model(dgp_ctx* ctx) {
+  for (auto& l : ctx->L) {
+    dev_free(l.Kuu); dev_free(l.Lu); dev_free(l.Linv); dev_free(l.Lq); dev_free(l.qmu_p); dev_free(l.Wcat);
+    dev_free(l.u); dev_free(l.Scat); dev_free(l.Z1); dev_free(l.Euu); dev_free(l.kdot); dev_free(l.dLq); dev_free(l.dqmu_p);
+  }
+  ctx->L.clear();
+  dev_free(ctx->params); dev_free(ctx->grad); dev_free(ctx->adam_m); dev_free(ctx->adam_v);
+  dev_free(ctx->segs_dev); dev_free(ctx->mean_params); dev_free(ctx->acc_own);
+  ctx->acc = nullptr;
+  for (auto& set : ctx->smset) for (auto& s : set) dev_free(s);
+  for (auto& z : ctx->zs_dev) dev_free(z);
+  ctx->zs_dev.clear(); ctx->zs_cap.clear();
+  for (int k = 0; k < 3; ++k) {
+    for (auto& o : ctx->out_dev[k]) dev_free(o);
+    ctx->out_dev[k].clear(); ctx->out_cap[k].clear();
+  }
+  ctx->n_params = 0;
+  ctx->grad_ready = false;
+  ctx->segs_uploaded = false;
+}
+
+inline long pad_rows(long P) { return round_up(P, 128); }
+
+// carve the chunk workspace; returns bytes needed.  base == nullptr: size query only
+size_t carve(dgp_ctx* ctx, char* base, long Nc, int S, bool train) {
+  size_t off = 0;
+  auto take = [&](long nd) -> double* {
+    double* p = base ? reinterpret_cast<double*>(base + off) : nullptr;
+    off += (size_t)round_up(nd * 8, 256);
+    return p;
+  };
+  const int nl = (int)ctx->L.size();
+  // Row counts of everything a row-parallel GEMM reads or writes are rounded up to the GEMM row tile (pad_rows):
+  // the products then run on whole tiles (no predicated edge strip: a 128-row strip of a K = D*Mp product is a
+  // 0.25 ms serial tail at multi-GPU shard sizes).  The pad rows hold garbage that never enters a reduction
+  // (those run over exactly Pl rows).
+  long Pmax_Mp = 0, pl_max = 0, xb_max = 0, x1_max = 0;
+  for (int l = 0; l < nl; ++l) {
+    Layer& y = ctx->L[l];
+    const long Pl = (l == 0) ? Nc : (long)S * Nc, Pm = pad_rows(Pl);
+    Pmax_Mp = std::max(Pmax_Mp, Pm * y.Mp);
+    pl_max = std::max(pl_max, Pm * (y.Mp / 32) * (1 + y.d.D_out));
+    xb_max = std::max(xb_max, (long)S * Nc * y.d.D_in);
+    x1_max = std::max(x1_max, Pm * (y.d.D_in + 1));
+  }
+  double *sKt = nullptr, *sCt = nullptr, *sPl = nullptr;
+  if (!train) { sKt = take(Pmax_Mp); sCt = take(Pmax_Mp); }
+  sPl = take(pl_max);                                      // row-norm partial planes: consumed within the layer
+  for (int l = 0; l < nl; ++l) {
+    Layer& y = ctx->L[l];
+    const long Pl = (l == 0) ? Nc : (long)S * Nc, Pm = pad_rows(Pl);
+    const long D = y.d.D_out;
+    if (train) { y.Kt = take(Pm * y.Mp); y.Ct = take(Pm * y.Mp); }
+    else { y.Kt = sKt; y.Ct = sCt; }
+    y.cnp = sPl;
+    y.tnp = sPl ? sPl + Pm * (y.Mp / 32) : nullptr;
+    y.mean0 = take(Pm * D); y.mean = take(Pl * D); y.var = take(Pl * D);
+    y.F = take((long)S * Nc * D);
+    if (train) { y.mbar = take(Pm * D); y.vbar = take(Pm * D); }
+    else { y.mbar = y.vbar = nullptr; }
+    y.Tt = (train && ctx->store_t) ? take(Pm * D * y.Mp) : nullptr;
+    y.Et = (train && y.d.kernel_kind != DGP_KERNEL_RBF) ? take(Pm * y.Mp) : nullptr;
+  }
+  if (train) {
+    ctx->Cbar = take(Pmax_Mp); ctx->Kbar = take(Pmax_Mp); ctx->Gt = take(Pmax_Mp); ctx->xbar = take(xb_max);
+    ctx->X1 = take(x1_max); ctx->R1 = take(x1_max);
+  }
+  return off;
+}
+
+int ensure_ws(dgp_ctx* ctx, long N, int S, bool train, long* Nc_out) {
+  const size_t per1 = carve(ctx, nullptr, 1024, S, train) / 1024 + 1;
+  long Nc = (long)((size_t)ctx->ws_limit / per1);
+  if (Nc < 1) Nc = 1;
+  if (Nc > N) Nc = N;
+  size_t need = carve(ctx, nullptr, Nc, S, train);
+  while (need > (size_t)ctx->ws_limit && Nc > 1) { Nc = Nc * 9 / 10; need = carve(ctx, nullptr, Nc, S, train); }
+  if (need > ctx->ws_cap) {
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    ctx->ws = nullptr; ctx->ws_cap = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&ctx->ws), need));
+    ctx->ws_cap = need;
+  }
+  carve(ctx, ctx->ws, Nc, S, train);
+  *Nc_out = Nc;
+  return DGP_OK;
+}
+
+int upload_zs(dgp_ctx* ctx, const double* const* zs, int S, long Ntot) {
+  const int nl = (int)ctx->L.size();
+  if ((int)ctx->zs_dev.size() < nl) { ctx->zs_dev.resize(nl, nullptr); ctx->zs_cap.resize(nl, 0); }
+  for (int l = 0; l < nl; ++l) {
+    if (!zs[l]) return fail(ctx, DGP_ERR_INVALID, "zs: NULL entry");
+    const size_t n = (size_t)S * Ntot * ctx->L[l].d.D_out;
+    RET(grow(ctx, &ctx->zs_dev[l], &ctx->zs_cap[l], n));
+    HIPCHK(hipMemcpyAsync(ctx->zs_dev[l], zs[l], n * 8, hipMemcpyHostToDevice, ctx->st));
+  }
+  return DGP_OK;
+}
+
+inline const double* P(dgp_ctx* ctx, long off) { return ctx->params + off; }
+
+// ------------------------------------------------------------------------------- prep: small matrices + KL
+int prep(dgp_ctx* ctx, bool train = false) {
+  HIPCHK(hipMemsetAsync(ctx->scal, 0, 4 * sizeof(double), ctx->st));
+  LayerFork fork(ctx, (int)ctx->L.size());
+  for (size_t li = 0; li < ctx->L.size(); ++li) {
+    Layer& y = ctx->L[li];
+    fork.use((int)li);
+    const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
+    const long MM = (long)Mp * Mp;
+    HIPCHK(pack_q(ctx->st, P(ctx, y.off_qsqrt), P(ctx, y.off_qmu), M, Mp, D, y.Lq, y.qmu_p));
+    HIPCHK(rbf_kuu(ctx->st, y.d.kernel_kind, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din, y.Kuu,
+                   train ? y.Euu : nullptr));
+    HIPCHK(copy_mat(ctx->st, y.Kuu, y.Lu, MM));
+    HIPCHK(potrf_inv(ctx->st, y.Lu, y.Linv, ctx->sm[9], Mp, 1, ctx->info));
+    if (y.d.white) {
+      HIPCHK(lq_to_wcat(ctx->st, y.Lq, Mp, D, y.Wcat));
+      HIPCHK(copy_mat(ctx->st, y.qmu_p, y.u, (long)Mp * D));
+    } else {
+      RET(G(ctx, 2, GEMM_NN, Mp, Mp, Mp, y.Linv, Mp, y.Lq, Mp, y.Wcat, (long)D * Mp, 1.0, 0, D, 0, MM, Mp));
+      RET(G(ctx, 2, GEMM_NN, Mp, D, Mp, y.Linv, Mp, y.qmu_p, D, y.u, D, 1.0, 0));
+    }
+    HIPCHK(layer_kl(ctx->st, y.Wcat, y.u, y.Lq, y.Lu, M, Mp, D, y.d.white, ctx->scal));
+    if (train) {
+      if (ctx->store_t) {
+        HIPCHK(wcat_transpose(ctx->st, y.Wcat, Mp, D, y.Scat));
+      } else {       // S'_d = W_d W_d^T - I  (symmetric), stacked [D*Mp x Mp]
+        GemmArgs a = mk(Mp, Mp, Mp, y.Wcat, (long)D * Mp, y.Wcat, (long)D * Mp, y.Scat, Mp);
+        a.batch = D; a.sA = Mp; a.sB = Mp; a.sC = MM;
+        RET(GX(ctx, 2, GEMM_NT, a));
+        HIPCHK(sub_identity(ctx->st, y.Scat, M, Mp, D));
+      }
+      HIPCHK(make_z1(ctx->st, P(ctx, y.off_Z), M, Mp, Din, y.Z1));
+    }
+  }
+  return DGP_OK;
+}
+
+ZSource zsrc_of(dgp_ctx* ctx, int l, bool use_zs, uint64_t seed, long n_goff, long Ntot) {
+  ZSource z;
+  z.zs = use_zs ? ctx->zs_dev[l] : nullptr;
+  z.seed = seed;
+  z.layer = l;
+  z.n_global0 = n_goff;
+  z.Ntot = Ntot;
+  return z;
+}
+
+// ------------------------------------------------------------------------------- forward over one chunk
+int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc, int S, uint64_t seed, bool use_zs,
+                  long n_goff) {
+  const int nl = (int)ctx->L.size();
+  for (int l = 0; l < nl; ++l) {
+    Layer& y = ctx->L[l];
+    const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
+    const bool dedup = (l == 0);
+    const long Pl = dedup ? Nc : (long)S * Nc, Pm = pad_rows(Pl);
+    const double* Xin = dedup ? Xsrc : ctx->L[l - 1].F;
+    const long row0 = dedup ? n0 : 0;
+    const int nplane = Mp / 32;
+    {
+      ProfScope ps(ctx, 1, 0, (double)Pl * (Mp + Din) * 8);
+      HIPCHK(rbf_kuf(ctx->st, y.d.kernel_kind, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
+                     y.Kt, y.Et));
+    }
+    const double tri1 = (double)Pl * Mp * (Mp + 1.0);   // 2 * M(M+1)/2 flops per point
+    {  // c = Lu^-1 k  and |c|^2 partials
+      GemmArgs a = mk(Pm, Mp, Mp, y.Kt, Mp, y.Linv, Mp, y.Ct, Mp);
+      a.tri = TRI_B_UPPER; a.triblk = Mp; a.epi = 2; a.rowsq = y.cnp; a.rowsq_ld = Pm;
+      RET(GX(ctx, 0, GEMM_NT, a, tri1, (double)Pl * Mp * 16));
+    }
+    {  // t_d = W_d^T c: |t_d|^2 partials always leave the kernel; t_d itself only for the backward pass (store_t)
+      GemmArgs a = mk(Pm, (long)D * Mp, Mp, y.Ct, Mp, y.Wcat, (long)D * Mp, y.Tt, (long)D * Mp);
+      a.tri = TRI_B_LOWER; a.triblk = Mp; a.epi = y.Tt ? 2 : 1; a.rowsq = y.tnp; a.rowsq_ld = Pm;
+      RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 8 * (y.Tt ? 1 + D : 1)));
+    }
+    RET(GX(ctx, 0, GEMM_NN, mk(Pm, D, Mp, y.Ct, Mp, y.u, D, y.mean0, D), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
+    {
+      ProfScope ps(ctx, 1, 0, (double)Pl * nplane * 8 * (1 + D));
+      HIPCHK(finalize_layer(ctx->st, y.cnp, y.tnp, nplane, Pm, y.mean0, Xin, row0, Pl, Nc, S, dedup ? 1 : 0, Din, D,
+                            P(ctx, y.off_var), y.d.mean_kind, y.meanW, y.meanb,
+                            zsrc_of(ctx, l, use_zs, seed, n_goff, Ntot), n0, y.mean, y.var, y.F));
+    }
+  }
+  return DGP_OK;
+}
+
+// ------------------------------------------------------------------------------- backward over one chunk
+// `params`: accumulate the parameter-gradient partial sums (training).  `xgrad0`: also produce the gradient with
+// respect to the first layer's inputs (ctx->xbar, [Nc x D_in0]) -- the vector-Jacobian product used on the
+// acquisition side (reference: tf.GradientTape on x, Infill_criteria.py:79-85).
+struct BwdOpts {
+  const double* X;   // inputs of the first layer (device), all Ntot rows
+  long Ntot;
+  long n_goff;
+  bool params;
+  bool xgrad0;
+};
+
+int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool use_zs, const BwdOpts& o) {
+  const int nl = (int)ctx->L.size();
+  double* acc = ctx->acc;
+  for (int l = nl - 1; l >= 0; --l) {
+    Layer& y = ctx->L[l];
+    const int Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
+    const bool dedup = (l == 0);
+    const long Pl = dedup ? Nc : (long)S * Nc, Pm = pad_rows(Pl);
+    const double* Xin = dedup ? o.X : ctx->L[l - 1].F;
+    const long row0 = dedup ? n0 : 0;
+    const long DM = (long)D * Mp, MM = (long)Mp * Mp;
+    const double tri1 = (double)Pl * Mp * (Mp + 1.0);
+    if (y.Tt) {  // dC = sum_d 2 vbar_d (W_d t_d - c): [2 vbar .* T] * WTcat, W_d lower => k <= n per block; "- c" in the epilogue
+      GemmArgs a = mk(Pm, Mp, DM, y.Tt, DM, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);
+      a.ascale = y.vbar; a.as_ld = D; a.a_kblk = Mp; a.ascale_mode = 1; a.a_wrap = 0;
+      a.tri = TRI_B_UPPER; a.triblk = Mp;
+      a.eadd = y.Ct; a.eadd_nsc = D;
+      a.rowf = y.mbar; a.colf = y.u; a.rank = D;             // + mbar u^T in the epilogue
+      RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 8 * (2 + D)));
+    } else {  // dC = sum_d 2 vbar_d .* (C S'_d)      (A operand scaled on the fly; K = D*Mp re-reads C per block)
+      GemmArgs a = mk(Pm, Mp, DM, y.Ct, Mp, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);
+      a.ascale = y.vbar; a.as_ld = D; a.a_kblk = Mp; a.ascale_mode = 1; a.a_wrap = 2;
+      a.rowf = y.mbar; a.colf = y.u; a.rank = D;             // + mbar u^T in the epilogue
+      // algorithmic count: the D triangular products W_d t_d of SURVEY App. C (the dense S' form executes 2x that)
+      RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 16));
+    }
+    {
+      GemmArgs a = mk(Pm, Mp, Mp, ctx->Cbar, Mp, y.Linv, Mp, ctx->Kbar, Mp);
+      a.tri = TRI_B_LOWER; a.triblk = Mp;
+      a.emul = y.Et ? y.Et : y.Kt; a.C2 = ctx->Gt;          // g = dK .* e (e = -2 dk/dr2; = k for the squared exponential)
+      RET(GX(ctx, 0, GEMM_NN, a, tri1, (double)Pl * Mp * 32));
+    }
+    // reductions over the chunk's points (accumulate into the all-reduce buffer)
+    if (o.params) {
+    {  // G_d = sum_p vbar_pd c_p c_p^T   (lower triangle; dW_d = 2 G_d W_d after the all-reduce)
+      GemmArgs a = mk(Mp, Mp, Pl, y.Ct, Mp, y.Ct, Mp, acc + y.acc_G, Mp, 1.0, 1);
+      a.batch = D; a.sC = MM; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp) * D, Pl, (long)Mp * 8);
+      a.ascale = y.vbar; a.as_ld = D; a.ascale_mode = 2;
+      RET(GX(ctx, 0, GEMM_TN, a, tri1 * D, (double)Pl * Mp * 8));
+    }
+    {
+      GemmArgs a = mk(Mp, Mp, Pl, ctx->Kbar, Mp, y.Ct, Mp, acc + y.acc_Q, Mp, 1.0, 1);
+      a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp), Pl, (long)Mp * 16);
+      RET(GX(ctx, 0, GEMM_TN, a, tri1, (double)Pl * Mp * 16));
+    }
+    {
+      GemmArgs a = mk(Mp, D, Pl, y.Ct, Mp, y.mbar, D, acc + y.acc_du, D, 1.0, 1);
+      a.splits = pick_splits(ctx, Mp, D, Pl);
+      RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
+    }
+    }
+    {  // RBF backward through Kuf: two skinny contractions of g with [Z | 1] and [X | 1]
+      const int w1 = Din + 1;
+      {
+        ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 16);
+        HIPCHK(make_x1(ctx->st, Xin, row0, Pl, Din, ctx->X1));
+      }
+      RET(GX(ctx, 0, GEMM_NN, mk(Pm, w1, Mp, ctx->Gt, Mp, y.Z1, w1, ctx->R1, w1), 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
+      if (o.params) {
+        GemmArgs a = mk(Mp, w1, Pl, ctx->Gt, Mp, ctx->X1, w1, acc + y.acc_GX, w1, 1.0, 1);
+        a.splits = pick_splits(ctx, Mp, w1, Pl);
+        RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
+      }
+      ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 24);
+      HIPCHK(xbar_finish(ctx->st, ctx->R1, ctx->X1, Pl, P(ctx, y.off_ls), Din, D, y.d.mean_kind, y.meanW, y.mbar,
+                         (l > 0 || o.xgrad0) ? 1 : 0, ctx->xbar, o.params ? acc + y.acc_x2 : nullptr));
+    }
+    if (l > 0) {
+      Layer& w = ctx->L[l - 1];
+      ProfScope ps(ctx, 1, 0, (double)S * Nc * Din * 24);
+      HIPCHK(fold_sample_grad(ctx->st, ctx->xbar, w.var, Nc, S, (l - 1 == 0) ? 1 : 0, w.d.D_out,
+                              zsrc_of(ctx, l - 1, use_zs, seed, o.n_goff, o.Ntot), n0, w.mbar, w.vbar,
+                              o.params ? acc + w.acc_dvar : nullptr));
+    }
+  }
+  return DGP_OK;
+}
+
+int check_flags(dgp_ctx* ctx) {
+  int h = 0;
+  HIPCHK(hipMemcpyAsync(&h, ctx->info, sizeof(int), hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  if (h) {
+    HIPCHK(hipMemsetAsync(ctx->info, 0, sizeof(int), ctx->st));
+    return fail(ctx, DGP_ERR_NOT_PD, "Cholesky: matrix is not positive definite");
+  }
+  return DGP_OK;
+}
+
+}  // namespace
+
