@@ -218,7 +218,7 @@ class DGP_Base:
             ctx = self._grad_step(data)
             ctx.adam_step(lr, beta_1, beta_2, epsilon, self._trainable_flags())
             self._device_newer = True
-            if step % messages == 0:
+            if messages and step % messages == 0:
                 self._say(f"ELBO: {ctx.last_elbo()}")
             if natgrad is not None:
                 gamma, mask = natgrad

@@ -667,3 +667,39 @@ def test_exact_gp_regression_matches_oracle(kind):
     l0 = m.training_loss()
     l1 = m.optimize_adam(iterations=30, lr=0.02)
     assert m.training_loss() < l0 and np.isfinite(l1)
+
+
+@pytest.mark.parametrize("surrogate", ["dgp", "gpr"])
+def test_bayesian_optimisation_iteration_without_tensorflow(surrogate, capsys):
+    """The loop body of SO_BO.run (SO_BO.py:270-313) on this package alone: build the surrogate as SO_BO.make_model does
+    (Z = X for the DGP; GPR for num_layers == 0), train it, maximise EI by DE then Adam, evaluate, append, re-assign
+    `model.data` (SO_BO.py:288)."""
+    from dgp_dace import Infill_criteria as IC
+    from dgp_dace.gpflow_compat import RBF, Gaussian, Matern52
+    from dgp_dace.models.dgp import DGP
+    from dgp_dace.models.gpr import GPR
+    f = lambda x: np.sin(3.0 * x[:, :1]) + 0.5 * x[:, 1:2] ** 2
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-1, 1, (12, 2))
+    Y = f(X)
+    lo, hi = np.array([-1.0, -1.0]), np.array([1.0, 1.0])
+    best0 = float(Y.min())
+    for it in range(2):
+        Yn = (Y - Y.mean(0)) / Y.std(0)                                          # SO_BO.normalize
+        if surrogate == "dgp":
+            model = DGP(X, Yn, X, [Matern52(1.0, [1.0, 1.0]), RBF(1.0, [1.0, 1.0])], [2], Gaussian(), num_samples=5)
+            model.optimize_nat_adam(iterations1=5, iterations2=15, beta_1=0.8, beta_2=0.9, lr_gamma=0.01, messages=0)
+            kw = dict(analytic=True, num_samples=32)
+        else:
+            model = GPR((X, Yn), Matern52(1.0, [1.0, 1.0]), noise_variance=1e-5)
+            model.optimize_adam(iterations=20, lr=0.01)
+            kw = {}
+        crit = IC.EI(float(Yn.min()), 2)
+        x_new = crit.optimize(model, (lo, hi), popsize_DE=20, iterations_DE=6, iterations_adam=5, method='DE+Adam', seed=it, **kw)
+        x_new = x_new.reshape(1, 2)
+        assert np.all(x_new >= lo) and np.all(x_new <= hi) and np.all(np.isfinite(x_new))
+        X, Y = np.vstack([X, x_new]), np.vstack([Y, f(x_new)])
+        if surrogate == "dgp":
+            model.data = (X[:-1], Yn)          # re-assignment as SO_BO.py:288 does (here: same size, new object)
+            assert np.isfinite(model.ELBO())
+    assert X.shape == (14, 2) and float(Y.min()) <= best0
