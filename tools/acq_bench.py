@@ -43,3 +43,24 @@ for _ in range(reps):
     c._value_and_grad(m, cb, num_samples=S)
 dt = (time.perf_counter() - t) / reps
 print(f"EI value + gradient for 64 candidates, S={S} (P={64*S}): {dt*1e3:.2f} ms")
+
+# exact GP (num_layers == 0): one training-loss + gradient evaluation and one EI population evaluation
+from dgp_dace.models.gpr import GPR
+from dgp_dace.gpflow_compat import Matern52
+Ng = 1000
+Xg = rng.uniform(-1, 1, (Ng, D)); Yg = np.sin(Xg @ rng.standard_normal((D, 1)))
+gp = GPR((Xg, Yg), Matern52(1.0, np.ones(D)), noise_variance=1e-5)
+gp.loss_and_grad()
+t = time.perf_counter(); reps = 10
+for _ in range(reps):
+    gp.loss_and_grad()
+dt = (time.perf_counter() - t) / reps
+print(f"exact GP, N={Ng}, D={D}: training loss + gradient {dt*1e3:.2f} ms per Adam iteration")
+cg = IC.EI(float(Yg.min()), D)
+candg = rng.uniform(-1, 1, (pop, D))
+cg.run(gp, candg)
+t = time.perf_counter()
+for _ in range(reps):
+    cg.run(gp, candg)
+dt = (time.perf_counter() - t) / reps
+print(f"exact GP: EI over a population of {pop}: {dt*1e3:.2f} ms per generation")
