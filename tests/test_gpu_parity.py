@@ -131,7 +131,7 @@ def test_optimize_nat_adam_trajectory_on_notebook_model(ng_all, capsys):
     assert len(printed) == 7
     # ng_all=False lets Adam (epsilon 1e-7) act on inner-layer q_sqrt entries whose gradient is exactly
     # zero in exact arithmetic (strictly-lower part of tril(Kuu^-1 L_q) at L_q = 1e-3 chol(Kuu)): their
-    # ~1e-10 rounding noise (same level in the oracle and on the GPU, measured by tools/diag_notebook.py)
+    # ~1e-10 rounding noise (same level in the oracle and on the GPU, measured by tests/diag_notebook.py)
     # becomes ~1e-5 steps and, through Kuu^-1 ~ 1e6, ~1e-5 relative ELBO differences between ANY two
     # fp64 implementations.  The first evaluation is exact-to-rounding in both modes.
     assert abs(printed[0] - ref[0]) < 1e-9 * abs(ref[0])
