@@ -238,3 +238,125 @@ class WB2S(WB2):
     def _dscale(self, x):
         s = self._scale(x)
         return s * (1.0 - s)
+
+
+def _ev(zero_c, mean, var):
+    """Expected violation E[max(g - zero_c, 0)] for g ~ N(mean, var) as Infill_criteria.py:243-257 writes it
+    ((mu - c) Phi(z) + var * N(-c; -mu, sigma), z = (mu - c)/sigma), with its partials in mu and var."""
+    sd = np.sqrt(var)
+    z = (mean - zero_c) / sd
+    cdf, pdf = ndtr(z), np.exp(-0.5 * z * z) / _SQRT_2PI
+    return (mean - zero_c) * cdf + sd * pdf, cdf, pdf / (2.0 * sd)
+
+
+class EV_one_constraint(Infill_criteria):
+    """Expected violation of one constraint model (Infill_criteria.py:234-262); `run` returns +EV."""
+
+    num_samples_analytic = 500
+
+    def __init__(self, zero_c, d):
+        self.name = 'Expected Violation'
+        self.zero_c = zero_c
+        self.d = d
+        self.IC_optimized = None
+        self.x_opt = None
+
+    def _moments(self, model, x):
+        if model.name == 'gpr':
+            mean, var = self._gpr_moments(model, x)
+            return mean, var, None
+        Fm, Fv = (_np(a) for a in model.predict_y(x, num_samples=self.num_samples_analytic))
+        mean, var = _moments(Fm, Fv)
+        return mean, var, Fm
+
+    def run(self, model, x, analytic=True, num_samples=100):
+        self._check(model)
+        x = _np(x)
+        c = np.asarray(self.zero_c, dtype=np.float64)
+        if analytic:
+            mean, var, _ = self._moments(model, x)
+            return as_tensor(_ev(c, mean, var)[0])
+        F, _, _ = model.propagate(x, S=num_samples)
+        FL = _np(F[-1])
+        return as_tensor(np.where(FL - c < 0, 0.0, FL - c).mean(0))
+
+    def _value_and_grad(self, model, x, analytic=True, num_samples=100):
+        """(+EV [N,1], d sum(EV)/dx)"""
+        self._check(model, gradient=True)
+        c = np.asarray(self.zero_c, dtype=np.float64)
+        if analytic:
+            mean, var, Fm = self._moments(model, x)
+            ev, d_mean, d_var = _ev(c, mean, var)
+            if Fm is None:
+                return ev, _np(model.predict_vjp(x, d_mean, d_var))
+            mean_bar, var_bar = _moment_cotangents(Fm, mean, d_mean, d_var)
+            return ev, _np(model.propagate_vjp(x, S=self.num_samples_analytic, mean_bar=mean_bar, var_bar=var_bar))
+        F, _, _ = model.propagate(x, S=num_samples)
+        FL = _np(F[-1])
+        above = FL - c >= 0
+        return np.where(above, FL - c, 0.0).mean(0), _np(model.propagate_vjp(x, S=num_samples, f_bar=np.where(above, 1.0, 0.0) / FL.shape[0]))
+
+
+class EV(Infill_criteria):
+    """Expected violation over a list of constraint models and its combination with an unconstrained criterion
+    (Infill_criteria.py:264-316): a candidate whose largest expected violation exceeds `threshold` scores
+    sum(EV) + 10000, any other scores the criterion IC (minus EI, ...) of the objective model."""
+
+    def __init__(self, zero_c, d):
+        self.name = 'Expected Violation'
+        self.zero_c = zero_c
+        self.d = d
+        self.IC_optimized = None
+        self.x_opt = None
+
+    def run(self, model_C, x, analytic=True, num_samples=100):
+        cols = [_np(EV_one_constraint(self.zero_c[i], self.d).run(model_C[i], x, analytic=analytic, num_samples=num_samples))
+                for i in range(len(model_C))]
+        return as_tensor(np.concatenate(cols, 1))
+
+    def run_with_IC(self, IC, model_Y, model_C, x, threshold=0.1, analytic=True, num_samples=100):
+        ev = _np(self.run(model_C, x, analytic=analytic, num_samples=num_samples))
+        ic = _np(IC.run(model_Y, x)).reshape(ev.shape[0], -1)[:, :1]
+        bad = ev.max(1, keepdims=True) > threshold
+        return as_tensor(np.where(bad, ev.sum(1, keepdims=True) + 10000.0, ic))
+
+    def _value_and_grad_with_IC(self, IC, model_Y, model_C, x, threshold, analytic, num_samples):
+        parts = [EV_one_constraint(self.zero_c[i], self.d)._value_and_grad(model_C[i], x, analytic=analytic, num_samples=num_samples)
+                 for i in range(len(model_C))]
+        ev = np.concatenate([v for v, _ in parts], 1)
+        g_ev = sum(g for _, g in parts)
+        ic, g_ic = IC._value_and_grad(model_Y, x)
+        bad = ev.max(1, keepdims=True) > threshold
+        return np.where(bad, ev.sum(1, keepdims=True) + 10000.0, _np(ic).reshape(ev.shape[0], -1)[:, :1]), np.where(bad, g_ev, g_ic)
+
+    def optimize_with_IC(self, IC, model_Y, model_C, bounds, threshold=0.1, analytic=True, num_samples=100, popsize_DE=300,
+                         popstd_DE=1.5, iterations_DE=400, init_adam=None, iterations_adam=1000, method='DE', seed=None):
+        """Infill_criteria.py:287-316 (the reference hard-codes threshold 0.1 inside its objective; the argument is
+        honoured here)."""
+        lw, up = (np.asarray(b, dtype=np.float64).reshape(-1) for b in bounds)
+        to_x = lambda u: lw + (up - lw) / (1.0 + np.exp(u))
+        rng = np.random.default_rng(seed)
+        if method in ('DE', 'DE+Adam'):
+            f = lambda U: _np(self.run_with_IC(IC, model_Y, model_C, to_x(U), threshold, analytic, num_samples)).reshape(U.shape[0], -1).sum(1)
+            u_best = _differential_evolution(f, np.zeros(self.d), popstd_DE, popsize_DE, iterations_DE, rng)
+            self.x_opt = to_x(u_best).reshape(self.d, 1)
+            self.IC_optimized = self.run_with_IC(IC, model_Y, model_C, self.x_opt.reshape(1, self.d), threshold, analytic, num_samples)
+        if method in ('Adam', 'DE+Adam'):
+            if init_adam is None:
+                init_adam = np.zeros(self.d) if self.x_opt is None else self.x_opt
+            x0 = np.asarray(init_adam, dtype=np.float64).reshape(-1)
+            u = np.log((up - x0 + 1e-3) / (x0 - lw + 1e-3))
+            m, v = np.zeros_like(u), np.zeros_like(u)
+            objective = None
+            for step in range(1, iterations_adam + 1):
+                e = np.exp(u)
+                x = lw + (up - lw) / (1.0 + e)
+                objective, gx = self._value_and_grad_with_IC(IC, model_Y, model_C, x.reshape(1, self.d), threshold, analytic, num_samples)
+                g = gx.reshape(-1) * (-(up - lw) * e / (1.0 + e) ** 2)
+                m = 0.9 * m + 0.1 * g
+                v = 0.999 * v + 0.001 * g * g
+                u = u - 0.01 * np.sqrt(1.0 - 0.999 ** step) / (1.0 - 0.9 ** step) * m / (np.sqrt(v) + 1e-7)
+            self.x_opt = to_x(u).reshape(self.d, 1)
+            self.IC_optimized = objective
+        return self.x_opt
+

@@ -703,3 +703,50 @@ def test_bayesian_optimisation_iteration_without_tensorflow(surrogate, capsys):
             model.data = (X[:-1], Yn)          # re-assignment as SO_BO.py:288 does (here: same size, new object)
             assert np.isfinite(model.ELBO())
     assert X.shape == (14, 2) and float(Y.min()) <= best0
+
+
+def test_constrained_infill_expected_violation_on_device_models():
+    """EV / run_with_IC / optimize_with_IC (Infill_criteria.py:234-316, the constrained loop of nb_dgp_BO cells 49-57)
+    with a DGP constraint model and an exact-GP objective model: values against the formula on the oracle's moments,
+    the gradient of the combined objective by finite differences, a DE+Adam optimisation inside the box."""
+    import gpr_oracle as G
+    from dgp_dace import Infill_criteria as IC
+    from dgp_dace.gpflow_compat import RBF
+    from dgp_dace.models.gpr import GPR
+    g = load(CASES[0])
+    mC = product_from_golden(g)                       # constraint surrogate: the golden DGP
+    oC = oracle_from_golden(g)
+    X, d = g["X"], g["X"].shape[1]
+    rng = np.random.default_rng(8)
+    Yobj = np.sin(X @ rng.standard_normal((d, 1)))
+    mY = GPR((X, Yobj), RBF(1.0, np.ones(d)), noise_variance=1e-4)
+    x = g["Xnew"][:5].copy()
+    zero_c = float(np.asarray(g["Y"]).mean())
+    ev1 = IC.EV_one_constraint(zero_c, d)
+    ev1.num_samples_analytic = 40
+    seed = mC.seed + 500
+    _pin(mC, seed)
+    got = np.asarray(ev1.run(mC, x))
+    zs = O.draw_zs(oC, seed, 40, x.shape[0])
+    _, Fm, Fv = oC.propagate(x, 40, zs)
+    mean, var = IC._moments(Fm[-1], Fv[-1] + float(g["lik_variance"]))
+    _close(got, IC._ev(zero_c, mean, var)[0], rtol=1e-9, atol=1e-11)
+    _pin(mC, seed)
+    val, gx = ev1._value_and_grad(mC, x)
+    dirn, h = rng.standard_normal(x.shape), 1e-5
+    f = []
+    for sg in (1, -1):
+        _pin(mC, seed)
+        f.append(float(np.asarray(ev1.run(mC, x + sg * h * dirn)).sum()))
+    fd = (f[0] - f[1]) / (2 * h)
+    assert abs(fd - float((gx * dirn).sum())) < 2e-6 * max(1.0, abs(fd))
+    # combination with EI on the exact-GP objective model
+    ev = IC.EV([zero_c], d)
+    ei = IC.EI(float(Yobj.min()) + 0.3, d)
+    thr = float(np.median(got))
+    _pin(mC, seed)
+    comb = np.asarray(ev.run_with_IC(ei, mY, [mC], x, threshold=thr, analytic=True, num_samples=40))
+    assert comb.shape == (5, 1) and (comb > 9000).any() and (comb < 9000).any()
+    x_opt = ev.optimize_with_IC(ei, mY, [mC], (X.min(0), X.max(0)), threshold=thr, popsize_DE=16, iterations_DE=4,
+                                iterations_adam=4, method='DE+Adam', seed=2)
+    assert x_opt.shape == (d, 1) and np.all(x_opt[:, 0] >= X.min(0)) and np.all(x_opt[:, 0] <= X.max(0))

@@ -249,3 +249,36 @@ def test_bench_flop_accounting_matches_the_survey_tables():
     assert X.shape == (1000, 3) and Y.shape == (1000, 1) and Z.shape == (16, 3)
     np.testing.assert_allclose(X.mean(0), 0, atol=1e-12)
     np.testing.assert_allclose(Y.std(0), 1, rtol=1e-12)
+
+
+def test_expected_violation_host_math():
+    """EV_one_constraint / EV (Infill_criteria.py:234-316): the reference's expression, its partials, and the
+    combination rule with an unconstrained criterion, on stub models (no device)."""
+    from scipy.stats import norm
+    from dgp_dace import Infill_criteria as IC
+    from dgp_dace.gpflow_compat import as_tensor
+    rng = np.random.default_rng(4)
+    mean, var, c = rng.standard_normal((6, 1)), rng.uniform(0.2, 1.5, (6, 1)), -0.3
+    ev, d_mean, d_var = IC._ev(c, mean, var)
+    sd = np.sqrt(var)
+    want = (-c + mean) * norm.cdf(-c, -mean, sd) + var * norm.pdf(-c, -mean, sd)        # Infill_criteria.py:246-248
+    np.testing.assert_allclose(ev, want, rtol=1e-13)
+    h = 1e-6
+    np.testing.assert_allclose(d_mean, (IC._ev(c, mean + h, var)[0] - IC._ev(c, mean - h, var)[0]) / (2 * h), rtol=1e-7)
+    np.testing.assert_allclose(d_var, (IC._ev(c, mean, var + h)[0] - IC._ev(c, mean, var - h)[0]) / (2 * h), rtol=1e-7)
+
+    class Stub:                                   # an exact-GP-like model with fixed predictions
+        name = 'gpr'
+        def __init__(self, m, v): self.m, self.v = m, v
+        def predict_y(self, x): return as_tensor(self.m[:len(x)]), as_tensor(self.v[:len(x)])
+    x = np.zeros((6, 2))
+    mc = [Stub(mean, var), Stub(mean + 1.0, var)]
+    e = IC.EV([c, c], 2)
+    evs = np.asarray(e.run(mc, x))
+    np.testing.assert_allclose(evs[:, :1], ev, rtol=1e-13)
+    my = Stub(rng.standard_normal((6, 1)), rng.uniform(0.2, 1.0, (6, 1)))
+    ei = IC.EI(0.1, 2)
+    got = np.asarray(e.run_with_IC(ei, my, mc, x, threshold=0.9))
+    bad = evs.max(1, keepdims=True) > 0.9
+    np.testing.assert_allclose(got, np.where(bad, evs.sum(1, keepdims=True) + 10000.0, np.asarray(ei.run(my, x))), rtol=1e-13)
+    assert bad.any() and (~bad).any()
