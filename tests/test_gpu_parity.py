@@ -750,3 +750,30 @@ def test_constrained_infill_expected_violation_on_device_models():
     x_opt = ev.optimize_with_IC(ei, mY, [mC], (X.min(0), X.max(0)), threshold=thr, popsize_DE=16, iterations_DE=4,
                                 iterations_adam=4, method='DE+Adam', seed=2)
     assert x_opt.shape == (d, 1) and np.all(x_opt[:, 0] >= X.min(0)) and np.all(x_opt[:, 0] <= X.max(0))
+
+
+def test_so_bo_constrained_run_on_the_notebook_problem(capsys):
+    """nb_dgp_BO.ipynb's problem (cells 4-6, 11, 15, 61): exact-GP objective, 2-layer DGP constraint, EI + EV,
+    DE+Adam, two iterations of SO_BO.run with small budgets; the bookkeeping the notebook prints must hold."""
+    from dgp_dace.BO.SO_BO import SO_BO
+
+    class Constrained_problem(object):
+        def __init__(self):
+            self.constraint = True
+            self.dim = 1
+        def fun(self, x):
+            return [(x - 0.5) ** 2, np.where(x > 0.25, 1.0, 0.0)]
+
+    bo = SO_BO(Constrained_problem(), DoE_size=5, model_Y_dic={'num_layers': 0, 'kernels': 'rbf'},
+               model_C_dic={'num_layers': 2, 'num_units': 1, 'kernels': 'rbf', 'num_samples': 10}, seed=1)
+    bo.train_model = lambda model, iteration=10: (model.optimize_adam(iterations=10) if model.name == 'gpr' else
+                                                  model.optimize_nat_adam(iterations1=3, iterations2=6, beta_1=0.8, beta_2=0.9,
+                                                                          lr_gamma=0.01, messages=3))
+    y0 = bo.Ymin[-1]
+    bo.run(2, from_scratch=3, IC='EI', train_iterations=10, popsize_DE=12, popstd_DE=3.0, threshold=0.1, iterations_DE=4,
+           constraint_handling='EV', iterations_adam=3, IC_method='DE+Adam', analytic=True)
+    out = capsys.readouterr().out
+    assert out.count('adding the most promising data point in iteration') == 2 and 'ELBO:' in out and 'Actual Y min:' in out
+    assert bo.X.shape == (7, 1) and bo.C.shape == (7, 1) and len(bo.Ymin) == 3
+    assert np.all(bo.X >= 0) and np.all(bo.X <= 1) and bo.Ymin[-1] <= y0
+    assert bo.model_C[0].data[0].shape[0] == 6            # the second iteration re-fed the grown data set

@@ -282,3 +282,48 @@ def test_expected_violation_host_math():
     bad = evs.max(1, keepdims=True) > 0.9
     np.testing.assert_allclose(got, np.where(bad, evs.sum(1, keepdims=True) + 10000.0, np.asarray(ei.run(my, x))), rtol=1e-13)
     assert bad.any() and (~bad).any()
+
+
+def test_so_bo_host_logic_without_a_device():
+    """Constructor, normalisation, feasibility bookkeeping and model factory of the BO driver mirror
+    (dgp_dace/BO/SO_BO.py against R/dgp_dace/BO/SO_BO.py:27-50,100-176,177-250); nothing here touches the GPU."""
+    from dgp_dace.BO.SO_BO import SO_BO, denormalize, normalize, normalize_C, normalize_X
+
+    class Problem:                                        # nb_dgp_BO.ipynb cells 4-6
+        constraint, dim = True, 1
+        def fun(self, x):
+            return [(x - 0.5) ** 2, np.where(x > 0.25, 1.0, 0.0)]
+
+    X = np.array([[0.05], [0.2], [0.4], [0.7], [0.9]])
+    Y, C = Problem().fun(X)
+    dgp_dic = {'num_layers': 2, 'num_units': 1, 'kernels': ['rbf', 'matern32', 'matern52'], 'num_samples': 10}
+    bo = SO_BO(Problem(), X=X, Y=Y, C=C, model_Y_dic={'num_layers': 0, 'kernels': 'rbf'}, model_C_dic=dgp_dic)
+    Xn, lw, up = normalize_X(X)
+    np.testing.assert_allclose(bo.X_train, Xn)
+    np.testing.assert_allclose(denormalize(bo.X_train, X), X, rtol=1e-13)
+    np.testing.assert_allclose([bo.lw_n, bo.up_n], [lw, up])
+    np.testing.assert_allclose(bo.feasible_0, normalize_C(C)[1])
+    np.testing.assert_allclose(bo.Y_train, normalize(Y))
+    assert bo.model_Y.name == 'gpr' and bo.model_C[0].name == 'dgp' and len(bo.model_C[0].layers) == 3
+    assert [l.kern.kind for l in bo.model_C[0].layers] == ['rbf', 'matern32', 'matern52']
+    assert bo.model_C[0].layers[0].feature.Z.shape == (5, 1)                        # Z = X (SO_BO.py:248)
+    np.testing.assert_allclose(bo.Xfeasible, [0.05, 0.2])                           # constraint <= 0 only below 0.25
+    assert np.isclose(bo.Ymin[-1], (0.2 - 0.5) ** 2)
+    with pytest.raises(Exception):
+        SO_BO(Problem(), X=X, Y=Y, C=C, model_Y_dic=None, model_C_dic=dgp_dic)
+    with pytest.raises(Exception):
+        bo.make_model({'num_layers': 2, 'num_units': [1], 'kernels': 'rbf', 'num_samples': 5}, Xn, normalize(Y))
+    # an infeasible proposal leaves the best value unchanged, a feasible better one updates it
+    bo.added_points = (np.array([[0.8]]) - X.mean(0)) / X.std(0)
+    bo.add_point()
+    assert bo.X.shape == (6, 1) and np.isclose(bo.X[-1, 0], 0.8) and np.isclose(bo.Ymin[-1], bo.Ymin[-2])
+    bo.added_points = (np.array([[0.24]]) - bo.X.mean(0)) / bo.X.std(0)
+    bo.add_point()
+    assert np.isclose(bo.Ymin[-1], (0.24 - 0.5) ** 2) and bo.X_train.shape == (7, 1) and bo.C_train.shape == (7, 1)
+    # unconstrained problems and a generated design
+    class Free:
+        constraint, dim = False, 2
+        def fun(self, x):
+            return [np.sum(x ** 2, 1, keepdims=True)]
+    bo2 = SO_BO(Free(), DoE_size=6, model_Y_dic={'num_layers': 1, 'num_units': 2, 'kernels': 'rbf', 'num_samples': 4}, seed=3)
+    assert bo2.X.shape == (6, 2) and bo2.C is None and np.isclose(bo2.Ymin[-1], bo2.Y.min())
