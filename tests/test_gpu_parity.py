@@ -777,3 +777,31 @@ def test_so_bo_constrained_run_on_the_notebook_problem(capsys):
     assert bo.X.shape == (7, 1) and bo.C.shape == (7, 1) and len(bo.Ymin) == 3
     assert np.all(bo.X >= 0) and np.all(bo.X <= 1) and bo.Ymin[-1] <= y0
     assert bo.model_C[0].data[0].shape[0] == 6            # the second iteration re-fed the grown data set
+
+
+def test_bench_py_multi_rank_launch_over_gloo(tmp_path):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per process, barrier +
+    max-over-ranks timing, one JSON line from rank 0), with two ranks sharing this GPU over gloo instead of RCCL:
+    the JSON contract must hold and the ELBO must equal the single-process run on the same (small) workload."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--N", "4000", "--M", "64", "--S", "4", "--num-units", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    port = 29700 + (os.getpid() % 2000)
+    env = dict(os.environ, DGP_BENCH_BACKEND="gloo")
+    cmd2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + args
+    r2 = subprocess.run(cmd2, env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    lines = [l for l in r2.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # ONE line, from rank 0
+    d2 = json.loads(lines[0])
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + args, capture_output=True, text=True,
+                        timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    for d, n in ((d1, 1), (d2, 2)):
+        assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "it/s" and d["dtype"] == "f64"
+        assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None and d["data"] == "synthetic"
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and "workload" in d["config"]
+        assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1) < 1e-9
+    assert abs(d1["elbo_last"] - d2["elbo_last"]) < 1e-10 * abs(d1["elbo_last"])
