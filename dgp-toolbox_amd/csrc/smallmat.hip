@@ -80,20 +80,29 @@ __global__ __launch_bounds__(64) void leaf_potrf_inv_kernel(double* __restrict__
         v = (v0 + v1) + (v2 + v3);
       }
       const double piv = __shfl(v, c);                 // pivot of this column (lane c)
-      const double rs = (piv > 0.0) ? 1.0 / sqrt(piv) : nan("");
+      // 1/sqrt(pivot) sits on the critical path of every column: hardware estimate + two Newton steps (a dependent
+      // fp64 operation costs ~30 cycles here; the library sqrt followed by a division is ~40 of them)
+      double rs = __builtin_amdgcn_rsq(piv);
+      rs = rs * (1.5 - 0.5 * piv * rs * rs);
+      rs = rs * (1.5 - 0.5 * piv * rs * rs);
+      if (!(piv > 0.0)) rs = nan("");
       if (i == c) {
         if (!(piv > 0.0)) atomicOr(info, 1);
-        Ls[c][c] = (piv > 0.0) ? sqrt(piv) : nan("");
+        Ls[c][c] = piv * rs;
       } else if (i > c && i < n) {
         Ls[i][c] = v * rs;
       }
       __syncthreads();
     }
   }
-  // inverse: thread j owns column j (forward substitution, everything in LDS)
+  // inverse: thread j owns column j (forward substitution, everything in LDS); the diagonal enters through its
+  // reciprocal, computed once per row instead of one division per element
+  __shared__ double dinv[LEAF];
+  if (i < n) dinv[i] = 1.0 / Ls[i][i];
+  __syncthreads();
   if (i < n) {
     const int j = i;
-    Xs[j][j] = 1.0 / Ls[j][j];
+    Xs[j][j] = dinv[j];
     for (int r = j + 1; r < n; ++r) {
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
       int k = j;
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(64) void leaf_potrf_inv_kernel(double* __restrict__
         s3 += Ls[r][k + 3] * Xs[k + 3][j];
       }
       for (; k < r; ++k) s0 += Ls[r][k] * Xs[k][j];
-      Xs[r][j] = -((s0 + s1) + (s2 + s3)) / Ls[r][r];
+      Xs[r][j] = -((s0 + s1) + (s2 + s3)) * dinv[r];
     }
   }
   __syncthreads();
