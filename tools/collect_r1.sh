@@ -14,9 +14,12 @@ tail -1 $O/smoke.log
 cd /tmp
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || { echo "pmc fetch failed"; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || { echo "pmc write failed"; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || { echo "pmc mfma failed"; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/stats_bench.json 2>/dev/null || { echo "stats failed"; exit 1; }
 cd $R
 python tools/summarize_r1.py $O $O/summary || { echo "summarize failed"; exit 1; }
 # the bench line proper reads the traffic figure measured just above
 DGP_TRAFFIC_JSON=$O/summary/r1_pmc_traffic.json timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err || { echo "bench failed"; tail -5 $O/bench.err; exit 1; }
 cat $O/bench.json
+timeout -k 10 400 python tools/configs_check.py > $O/summary/r1_other_configs.txt 2>&1 || { echo "configs_check failed"; tail -5 $O/summary/r1_other_configs.txt; exit 1; }
+cat $O/summary/r1_other_configs.txt

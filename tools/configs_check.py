@@ -16,7 +16,7 @@ def build(N, D, M, S, num_units):
 
 
 def timed(label, f, n):
-    f(); t0 = time.perf_counter()
+    f(); m.sync(); t0 = time.perf_counter()
     for _ in range(n): f()
     m.sync(); dt = (time.perf_counter() - t0) / n
     print(f"{label}: {1e3 * dt:.2f} ms/iteration = {1 / dt:.2f} it/s", flush=True)
@@ -45,6 +45,20 @@ def it2():
     c = m._grad_step(m.data); c.natgrad_step(0.01, mask)
 m.sync(); timed("config 2 (N=100k, D=8, M=256, [8,8]) nat_adam Part-2 iteration", it2, 5)
 print("config 2 ELBO after those iterations:", ctx.last_elbo(), flush=True)
+
+# config 2-alt: one hidden layer [8]
+m = build(100_000, 8, 256, 10, [8])
+for l in m.layers[:-1]: l.q_sqrt.assign(l.q_sqrt * 1e-3)
+ctx = m._sync_model(); ctx.adam_reset(); fl = m._trainable_flags()
+m.sync(); timed("config 2-alt (N=100k, D=8, M=256, [8]) adam iteration", it, 10)
+
+# config 4 shape, minibatch of 10 000 points per GPU
+m = build(10_000, 16, 512, 10, [16, 16, 16])
+mask = m._natgrad_setup(True)
+for l in m.layers[:-1]: l.q_sqrt.assign(l.q_sqrt * 1e-3)
+ctx = m._sync_model(); ctx.adam_reset(); fl = m._trainable_flags()
+m.sync(); timed("config 4 minibatch (10 000 points, D=16, M=512, [16,16,16]) adam iteration", it, 10)
+m.sync(); timed("config 4 minibatch (10 000 points, D=16, M=512, [16,16,16]) nat_adam Part-2 iteration", it2, 5)
 
 # config 4 shape, one GPU's share of N=1M over 8 GPUs: 4 SVGP layers, D=16, M=512
 m = build(125_000, 16, 512, 10, [16, 16, 16])

@@ -3,7 +3,8 @@
 
 usage: summarize_r1.py <collect dir> <out dir>
 Writes r1_kernel_stats.csv (the --stats table), r1_pmc_fetch_size.csv / r1_pmc_write_size.csv (per-kernel-name sums
-of the counters) and r1_pmc_traffic.json (HBM bytes per launch of the GEMM engine, corrected as
+of the counters), r1_pmc_mfma.json (matrix-pipe counters of the GEMM engine: executed fp64 MFMA flops, MFMA busy
+fraction, effective clock) and r1_pmc_traffic.json (HBM bytes per launch of the GEMM engine, corrected as
 MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE is in KB and gfx950 reports half of wide coalesced reads).
 """
 import csv, glob, json, os, shutil, sys
@@ -70,3 +71,45 @@ json.dump({
     "all_kernels_hbm_bytes_per_step": all_fetch / steps,
 }, open(os.path.join(out, "r1_pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(out, "r1_pmc_traffic.json")).read())
+
+
+# ---- matrix-pipe counters of the GEMM engine (third PMC pass) ----
+mfma_csv = glob.glob(os.path.join(src, "pmc_mfma/**/*_counter_collection.csv"), recursive=True)
+if mfma_csv:
+    per = defaultdict(lambda: defaultdict(float))          # dispatch -> counter -> value
+    names = {}
+    with open(mfma_csv[0], newline="") as f:
+        for row in csv.DictReader(f):
+            per[row["Dispatch_Id"]][row["Counter_Name"]] += float(row["Counter_Value"])
+            names[row["Dispatch_Id"]] = row["Kernel_Name"]
+    dur = {}
+    trace = glob.glob(os.path.join(src, "pmc_mfma/**/*_kernel_trace.csv"), recursive=True)
+    if trace:
+        with open(trace[0], newline="") as f:
+            for row in csv.DictReader(f):
+                dur[row["Dispatch_Id"]] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+    SIMDS, XCDS = 1024, 8
+    busy = mops = gui = ns = 0.0
+    big = []
+    for d, c in per.items():
+        if "gemm_f64_kernel" not in names[d]:
+            continue
+        busy += c["SQ_VALU_MFMA_BUSY_CYCLES"]; mops += c["SQ_INSTS_VALU_MFMA_MOPS_F64"]; gui += c["GRBM_GUI_ACTIVE"]
+        ns += dur.get(d, 0)
+        if dur.get(d, 0) > 5e6:
+            big.append({"kernel": names[d].split("(")[0][-60:], "ms": dur[d] / 1e6,
+                        "executed_tflops": c["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512 / dur[d] / 1e3,
+                        "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / XCDS * SIMDS),
+                        "clock_ghz": c["GRBM_GUI_ACTIVE"] / XCDS / dur[d]})
+    json.dump({
+        "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace, bench.py --steps 2 --warmup 1, config 2, 1 GPU",
+        "kernel": "dgp::gemm_f64_kernel (all instantiations, all launches of the 3 iterations)",
+        "formulas": "executed flops = MOPS_F64 x 512; MfmaUtil = MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs) (rocprofv3's own MfmaUtil expression); clock = GRBM_GUI_ACTIVE/8/duration",
+        "executed_mfma_flops_per_step": mops * 512 / steps,
+        "executed_tflops_over_gemm_time": mops * 512 / ns / 1e3 if ns else None,
+        "mfma_busy_frac": busy / (gui / XCDS * SIMDS) if gui else None,
+        "effective_clock_ghz": gui / XCDS / ns if ns else None,
+        "gemm_ms_per_step_profiled": ns / 1e6 / steps,
+        "launches_over_5ms_last_first": big[-12:],
+    }, open(os.path.join(out, "r1_pmc_mfma.json"), "w"), indent=1)
+    print(open(os.path.join(out, "r1_pmc_mfma.json")).read())
