@@ -32,8 +32,18 @@ static hipError_t launch(hipStream_t st, GemmArgs a) {
   const bool grouped = a.splits > 1 && a.splits % 8 == 0;
   long gx = tiles;
   static long gmax = 0;
-  if (gmax == 0) { const char* e = getenv("DGP_GEMM_GRID"); gmax = e ? atol(e) : 4088; if (gmax < 8) gmax = 8; }
-  if (!grouped && gx > gmax) gx = gmax;
+  static long gmin = 0, per = 4;
+  if (gmax == 0) {
+    const char* e = getenv("DGP_GEMM_GRID"); gmax = e ? atol(e) : 4088; if (gmax < 8) gmax = 8;
+    e = getenv("DGP_GEMM_GRID_MIN"); gmin = e ? atol(e) : 1016; if (gmin > gmax) gmin = gmax;
+    e = getenv("DGP_GEMM_TILES_PER_WG"); per = e ? atol(e) : 4; if (per < 1) per = 1;
+  }
+  if (!grouped && gx > gmin) {
+    // ~`per` tiles per workgroup amortise the launch cost of a workgroup, few enough workgroups leave the
+    // balancing of unequal (triangular) tiles to the hardware dispatcher: 8 * odd, between gmin and gmax
+    long want = ((tiles / per / 8) | 1) * 8;
+    gx = want < gmin ? gmin : (want > gmax ? gmax : want);
+  }
   dim3 grid((unsigned)gx, (unsigned)(a.batch * a.splits), 1);
   hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, VA, VB, FAST, SCALED>), grid, dim3(256), 0, st, a);
   return hipGetLastError();

@@ -9,7 +9,7 @@ last = rows[-n:]
 t0 = int(last[0]["Start_Timestamp"])
 for r in last:
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    if d < 100: continue
+    if d < float(sys.argv[3] if len(sys.argv) > 3 else 100): continue
     name = r["Kernel_Name"]
     short = name.split("(")[0][:90]
     print(f"{(int(r['Start_Timestamp'])-t0)/1e6:9.3f} ms  {d:10.1f} us  grid {r.get('Grid_Size_X', r.get('Grid_Size','?')):>8} wg {r.get('Workgroup_Size_X', r.get('Workgroup_Size','?')):>4}  {short}")
