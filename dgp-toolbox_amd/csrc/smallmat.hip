@@ -47,81 +47,87 @@ hipError_t rbf_kuu(hipStream_t st, int kind, const double* Z, const double* var,
 // triangular_solve on Kuu (layers.py:231,245-247) and GPflow's chol(-2 nat2), its inverse and chol(S).
 constexpr int LEAF = 64;
 
-// One wave per matrix: thread i owns row i; the matrix lives in LDS, so a barrier is a single-wave s_barrier.
-// Global reads and writes go row by row with the lanes along the row (coalesced), and the dot products carry four
-// independent partial sums (the dependent fp64 FMA chain was the critical path of the one-wave kernel).
+// One wave per matrix, the matrix in REGISTERS: lane i owns row i (64 doubles), every loop is unrolled so that the
+// row is addressed with compile-time indices, and a value of another row travels through v_readlane (an SGPR
+// operand of the FMA) instead of LDS.  The LDS version of this kernel (dot products over LDS rows, one barrier per
+// column) took ~100 us per 64 x 64 block and four of them sit on the critical path of every Kuu factorisation.
+//   Cholesky: right-looking; column c is scaled by 1/sqrt(pivot) and its outer product leaves the trailing rows.
+//   Inverse : rows of L are scaled to a unit diagonal (L' = D^-1 L), X' = L'^-1 by forward substitution IN PLACE
+//             (entry k of a row is consumed by step k and replaced by the entry of X'), then X = X' D^-1.
+// Global reads and writes go row by row with the lanes along the row (coalesced) through an LDS transpose.
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(64) void leaf_potrf_inv_kernel(double* __restrict__ Aall, double* __restrict__ Xall, int ld,
                                                             long stride, int off, int n, int do_chol,
                                                             int* __restrict__ info) {
-  __shared__ double Ls[LEAF][LEAF + 1];
-  __shared__ double Xs[LEAF][LEAF + 1];
+  __shared__ double T[LEAF][LEAF + 1];
   double* A = Aall + (long)blockIdx.x * stride + (long)off * ld + off;
   double* X = Xall + (long)blockIdx.x * stride + (long)off * ld + off;
   const int i = threadIdx.x;
-  for (int r = 0; r < n; ++r) {
-    if (i < n) Ls[r][i] = (i <= r) ? A[(long)r * ld + i] : 0.0;
-    Xs[r][i] = 0.0;
-  }
+  for (int r = 0; r < n; ++r)
+    if (i < n) T[r][i] = A[(long)r * ld + i];
   __syncthreads();
+  double a[LEAF];
+  // rows and columns beyond n behave as an identity block
+#pragma unroll
+  for (int j = 0; j < LEAF; ++j) {
+    const double v = T[i < n ? i : 0][j];
+    a[j] = (i < n && j < n) ? (j <= i ? v : 0.0) : (i == j ? 1.0 : 0.0);
+  }
+  double diag = 1.0;
   if (do_chol) {
-    // left-looking by columns: column c needs the finished columns 0..c-1 only -> one barrier per column
-    for (int c = 0; c < n; ++c) {
-      double v = 0.0;
-      if (i >= c && i < n) {
-        double v0 = Ls[i][c], v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        int k = 0;
-        for (; k + 3 < c; k += 4) {
-          v0 -= Ls[i][k] * Ls[c][k];
-          v1 -= Ls[i][k + 1] * Ls[c][k + 1];
-          v2 -= Ls[i][k + 2] * Ls[c][k + 2];
-          v3 -= Ls[i][k + 3] * Ls[c][k + 3];
-        }
-        for (; k < c; ++k) v0 -= Ls[i][k] * Ls[c][k];
-        v = (v0 + v1) + (v2 + v3);
-      }
-      const double piv = __shfl(v, c);                 // pivot of this column (lane c)
-      // 1/sqrt(pivot) sits on the critical path of every column: hardware estimate + two Newton steps (a dependent
-      // fp64 operation costs ~30 cycles here; the library sqrt followed by a division is ~40 of them)
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < LEAF; ++c) {
+      const double piv = lane_bcast(a[c], c);
+      // 1/sqrt(pivot): hardware estimate + two Newton steps (a library sqrt and a division are ~40 dependent
+      // fp64 operations on the critical path of every column)
       double rs = __builtin_amdgcn_rsq(piv);
       rs = rs * (1.5 - 0.5 * piv * rs * rs);
       rs = rs * (1.5 - 0.5 * piv * rs * rs);
-      if (!(piv > 0.0)) rs = nan("");
-      if (i == c) {
-        if (!(piv > 0.0)) atomicOr(info, 1);
-        Ls[c][c] = piv * rs;
-      } else if (i > c && i < n) {
-        Ls[i][c] = v * rs;
-      }
-      __syncthreads();
+      if (!(piv > 0.0)) { rs = nan(""); bad = true; }
+      const double l = (i >= c) ? a[c] * rs : 0.0;       // column c of L (zero above the diagonal)
+      a[c] = l;
+      if (i == c) diag = l;
+#pragma unroll
+      for (int j = c + 1; j < LEAF; ++j) a[j] = fma(-l, lane_bcast(l, j), a[j]);   // only j <= i is meaningful
     }
+    if (bad && i == 0) atomicOr(info, 1);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < LEAF; ++j) T[i][j] = a[j];
+    __syncthreads();
+    for (int r = 0; r < n; ++r)
+      if (i < n) A[(long)r * ld + i] = T[r][i];
+  } else {
+#pragma unroll
+    for (int j = 0; j < LEAF; ++j) diag = (i == j) ? a[j] : diag;
   }
-  // inverse: thread j owns column j (forward substitution, everything in LDS); the diagonal enters through its
-  // reciprocal, computed once per row instead of one division per element
-  __shared__ double dinv[LEAF];
-  if (i < n) dinv[i] = 1.0 / Ls[i][i];
+  const double dinv = 1.0 / diag;
+#pragma unroll
+  for (int k = 0; k < LEAF; ++k) a[k] = (i > k) ? a[k] * dinv : 0.0;      // strictly lower part of L' = D^-1 L
+#pragma unroll
+  for (int k = 0; k < LEAF; ++k) {
+    const double m = a[k];                                  // L'[i][k] for the rows below k, 0 for the others
+#pragma unroll
+    for (int j = 0; j < k; ++j) a[j] = fma(-m, lane_bcast(a[j], k), a[j]);   // row k of X' is final in lane k
+    a[k] = -m;
+  }
+#pragma unroll
+  for (int j = 0; j < LEAF; ++j) {
+    const double dj = lane_bcast(dinv, j);
+    a[j] = (i > j) ? a[j] * dj : (i == j ? dinv : 0.0);
+  }
   __syncthreads();
-  if (i < n) {
-    const int j = i;
-    Xs[j][j] = dinv[j];
-    for (int r = j + 1; r < n; ++r) {
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int k = j;
-      for (; k + 3 < r; k += 4) {
-        s0 += Ls[r][k] * Xs[k][j];
-        s1 += Ls[r][k + 1] * Xs[k + 1][j];
-        s2 += Ls[r][k + 2] * Xs[k + 2][j];
-        s3 += Ls[r][k + 3] * Xs[k + 3][j];
-      }
-      for (; k < r; ++k) s0 += Ls[r][k] * Xs[k][j];
-      Xs[r][j] = -((s0 + s1) + (s2 + s3)) * dinv[r];
-    }
-  }
+#pragma unroll
+  for (int j = 0; j < LEAF; ++j) T[i][j] = a[j];
   __syncthreads();
   for (int r = 0; r < n; ++r)
-    if (i < n) {
-      if (do_chol) A[(long)r * ld + i] = Ls[r][i];
-      X[(long)r * ld + i] = Xs[r][i];
-    }
+    if (i < n) X[(long)r * ld + i] = T[r][i];
 }
 
 // batched strided block copy: dst[b][r][c] = src[b][r][c] for an nr x nc block (leading dimension ld, batch stride)
