@@ -87,9 +87,11 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
   int Mpmax = 0, Dmax = 0;
   for (int l = 0; l < n_layers; ++l) {
     const dgp_layer_desc& d = layers[l];
-    if (d.D_in <= 0 || d.D_in > 64 || d.D_out <= 0 || d.M <= 0 || d.M > 1024 || d.D_out > 65535 || d.kernel_kind < DGP_KERNEL_RBF || d.kernel_kind > DGP_KERNEL_MATERN52 ||
-        d.mean_kind < 0 || d.mean_kind > 2)
-      return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: unsupported layer description (RBF kernel, M <= 1024, D_in <= 64)");
+    if (d.D_in <= 0 || d.D_in > 64 || d.D_out <= 0 || d.M <= 0 || d.M > 1024 || d.D_out > 65535 || d.kernel_kind < DGP_KERNEL_RBF || d.kernel_kind > DGP_KERNEL_MF ||
+        d.mean_kind < 0 || d.mean_kind > 2 || d.kernel_white < 0 || d.kernel_white > 1)
+      return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: unsupported layer description (M <= 1024, D_in <= 64)");
+    if (d.kernel_kind == DGP_KERNEL_MF && (d.D_in < 2 || d.D_in > 33 || d.mean_kind != DGP_MEAN_ZERO))
+      return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: the multi-fidelity kernel needs 2 <= D_in <= 33 and a zero mean function");
     if (l > 0 && d.D_in != layers[l - 1].D_out) return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: layer dims do not chain");
     if (d.mean_kind == DGP_MEAN_IDENTITY && d.D_in != d.D_out)
       return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: identity mean needs D_in == D_out");
@@ -98,7 +100,8 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
     y.Mp = (int)round_up(d.M, 64);   // tiles of 64 columns never straddle an output block
     y.off_Z = off; off += (long)d.M * d.D_in;
     y.off_var = off; off += 1;
-    y.off_ls = off; off += d.D_in;
+    y.off_ls = off; off += (d.kernel_kind == DGP_KERNEL_MF) ? 6 : d.D_in;
+    if (d.kernel_white) { y.off_white = off; off += 1; }
     y.off_qmu = off; off += (long)d.M * d.D_out;
     y.off_qsqrt = off; off += (long)d.D_out * d.M * d.M;
     const long MM = (long)y.Mp * y.Mp;
@@ -106,7 +109,7 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
     y.acc_G = aoff; aoff += MM * d.D_out;
     y.acc_du = aoff; aoff += round_up((long)y.Mp * d.D_out, 2);
     y.acc_GX = aoff; aoff += round_up((long)y.Mp * (d.D_in + 1), 2);
-    y.acc_x2 = aoff; aoff += round_up(d.D_in, 2);
+    y.acc_x2 = aoff; aoff += round_up(std::max(d.D_in, 8), 2);   // DGP_KERNEL_MF keeps its 7 parameter sums here
     y.acc_dvar = aoff; aoff += 2;
     Mpmax = std::max(Mpmax, y.Mp);
     Dmax = std::max(Dmax, d.D_out);
@@ -144,7 +147,7 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
     RET(dev_alloc(ctx, &y.Kuu, MM)); RET(dev_alloc(ctx, &y.Lu, MM)); RET(dev_alloc(ctx, &y.Linv, MM));
     RET(dev_alloc(ctx, &y.Lq, MM * D)); RET(dev_alloc(ctx, &y.qmu_p, (long)y.Mp * D));
     RET(dev_alloc(ctx, &y.Wcat, MM * D)); RET(dev_alloc(ctx, &y.u, (long)y.Mp * D)); RET(dev_alloc(ctx, &y.Scat, MM * D)); RET(dev_alloc(ctx, &y.Z1, (long)y.Mp * (y.d.D_in + 1)));
-    if (y.d.kernel_kind != DGP_KERNEL_RBF) { RET(dev_alloc(ctx, &y.Euu, MM)); RET(dev_alloc(ctx, &y.kdot, 1)); }
+    if (y.d.kernel_kind == DGP_KERNEL_MATERN32 || y.d.kernel_kind == DGP_KERNEL_MATERN52) { RET(dev_alloc(ctx, &y.Euu, MM)); RET(dev_alloc(ctx, &y.kdot, 1)); }
     RET(dev_alloc(ctx, &y.dLq, MM * D)); RET(dev_alloc(ctx, &y.dqmu_p, (long)y.Mp * D));
     if (y.d.mean_kind == DGP_MEAN_LINEAR) {
       y.meanW = ctx->mean_params + moff; moff += (long)y.d.D_in * D;
@@ -152,7 +155,8 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
     }
     ctx->segs.push_back({y.off_Z, (long)y.d.M * y.d.D_in, TR_IDENTITY, 1, 0});
     ctx->segs.push_back({y.off_var, 1, TR_SOFTPLUS, 1, 0});
-    ctx->segs.push_back({y.off_ls, y.d.D_in, TR_SOFTPLUS, 1, 0});
+    ctx->segs.push_back({y.off_ls, (y.d.kernel_kind == DGP_KERNEL_MF) ? 6L : (long)y.d.D_in, TR_SOFTPLUS, 1, 0});
+    if (y.off_white >= 0) ctx->segs.push_back({y.off_white, 1, TR_SOFTPLUS, 1, 0});
     ctx->segs.push_back({y.off_qmu, (long)y.d.M * D, TR_IDENTITY, 1, 0});
     ctx->segs.push_back({y.off_qsqrt, (long)D * y.d.M * y.d.M, TR_TRIL, 1, y.d.M});
   }
@@ -293,6 +297,9 @@ int dgp_propagate_full_cov(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t
   double *Kt = nullptr, *Ct = nullptr, *T = nullptr, *mean0 = nullptr, *mean = nullptr, *Kff = nullptr, *V = nullptr,
          *Vinv = nullptr, *tmp = nullptr, *var_dev = nullptr, *Fa = nullptr, *Fb = nullptr, *X0 = nullptr;
   const long NN = (long)Np * Np;
+  for (auto& y : ctx->L)
+    if (y.d.kernel_kind == DGP_KERNEL_MF || y.off_white >= 0)
+      return fail(ctx, DGP_ERR_INVALID, "dgp_propagate_full_cov: stationary kernels without a White term only");
   struct Free {
     std::vector<double**> ps;
     ~Free() { for (auto p : ps) dev_free(*p); }
@@ -358,10 +365,11 @@ int dgp_propagate_full_cov(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t
   return check_flags(ctx);
 }
 
-int dgp_propagate_vjp(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
-                      const double* f_bar, const double* mean_bar, const double* var_bar, double* xbar_out) {
+static int vjp_body(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
+                    const double* f_bar, const double* mean_bar, const double* var_bar, double* xbar_out, bool params,
+                    bool reset) {
   RET(check_ready(ctx, false));
-  if (!Xnew || !xbar_out || Nn <= 0 || S <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_propagate_vjp: bad arguments");
+  if (!Xnew || (!xbar_out && !params) || Nn <= 0 || S <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_propagate_vjp: bad arguments");
   if (!f_bar && !mean_bar && !var_bar) return fail(ctx, DGP_ERR_INVALID, "dgp_propagate_vjp: no cotangent given");
   HIPCHK(hipSetDevice(ctx->device));
   const int nl = (int)ctx->L.size();
@@ -383,6 +391,10 @@ int dgp_propagate_vjp(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, u
     dev_bar[k] = ctx->out_dev[k][nl - 1];
   }
   RET(prep(ctx, true));
+  if (params) {
+    ctx->grad_ready = false;
+    if (reset) HIPCHK(hipMemsetAsync(ctx->acc, 0, ctx->n_acc * 8, ctx->st));
+  }
   long Nc = 0;
   RET(ensure_ws(ctx, Nn, S, true, &Nc));
   const bool dedup_last = nl == 1;
@@ -392,12 +404,26 @@ int dgp_propagate_vjp(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, u
     {
       ProfScope ps(ctx, 1, 0, 0);
       HIPCHK(vjp_seed(ctx->st, dev_bar[0], dev_bar[1], dev_bar[2], last.var, nc, S, dedup_last ? 1 : 0, DL,
-                      zsrc_of(ctx, nl - 1, zs != nullptr, seed, 0, Nn), Nn, n0, last.mbar, last.vbar));
+                      zsrc_of(ctx, nl - 1, zs != nullptr, seed, 0, Nn), Nn, n0, last.mbar, last.vbar,
+                      params ? ctx->acc + last.acc_dvar : nullptr));
     }
-    RET(backward_chunk(ctx, n0, nc, S, seed, zs != nullptr, BwdOpts{ctx->Xnew, (long)Nn, 0, false, true}));
-    HIPCHK(hipMemcpyAsync(xbar_out + n0 * Din0, ctx->xbar, (size_t)nc * Din0 * 8, hipMemcpyDeviceToHost, ctx->st));
+    RET(backward_chunk(ctx, n0, nc, S, seed, zs != nullptr, BwdOpts{ctx->Xnew, (long)Nn, 0, params, true}));
+    if (xbar_out)
+      HIPCHK(hipMemcpyAsync(xbar_out + n0 * Din0, ctx->xbar, (size_t)nc * Din0 * 8, hipMemcpyDeviceToHost, ctx->st));
   }
   return check_flags(ctx);
+}
+
+int dgp_propagate_vjp(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
+                      const double* f_bar, const double* mean_bar, const double* var_bar, double* xbar_out) {
+  if (!xbar_out) return fail(ctx, DGP_ERR_INVALID, "dgp_propagate_vjp: bad arguments");
+  return vjp_body(ctx, Xnew, Nn, S, seed, zs, f_bar, mean_bar, var_bar, xbar_out, false, false);
+}
+
+int dgp_vjp_accumulate(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
+                       const double* f_bar, const double* mean_bar, const double* var_bar, double* xbar_out,
+                       int32_t reset) {
+  return vjp_body(ctx, Xnew, Nn, S, seed, zs, f_bar, mean_bar, var_bar, xbar_out, true, reset != 0);
 }
 
 int dgp_grad_partial(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs) {
@@ -483,10 +509,16 @@ int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out) {
     HIPCHK(phi_tril_halfdiag(ctx->st, T3, Mp, 1));
     RET(G(ctx, 2, GEMM_NN, Mp, Mp, Mp, T3, Mp, y.Linv, Mp, T4, Mp, 1.0, 0));
     RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Linv, Mp, T4, Mp, Sm, Mp, 1.0, 0));
-    HIPCHK(rbf_kuf_bwd_finish(ctx->st, acc + y.acc_GX, acc + y.acc_x2, acc + y.acc_dvar, P(ctx, y.off_Z), P(ctx, y.off_var),
-                              P(ctx, y.off_ls), M, Din, g + y.off_Z, g + y.off_ls, g + y.off_var, y.kdot));
-    HIPCHK(rbf_kuu_bwd(ctx->st, Sm, y.Kuu, y.Euu, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
-                       g + y.off_Z, g + y.off_ls, g + y.off_var));
+    if (y.d.kernel_kind == DGP_KERNEL_MF) {
+      HIPCHK(mf_collect(ctx->st, acc + y.acc_GX, acc + y.acc_x2, M, Din, g + y.off_Z, g + y.off_var));
+      HIPCHK(mf_kuu_bwd(ctx->st, Sm, P(ctx, y.off_Z), P(ctx, y.off_var), M, Mp, Din, g + y.off_Z, g + y.off_var));
+    } else {
+      HIPCHK(rbf_kuf_bwd_finish(ctx->st, acc + y.acc_GX, acc + y.acc_x2, acc + y.acc_dvar, P(ctx, y.off_Z), P(ctx, y.off_var),
+                                P(ctx, y.off_ls), M, Din, g + y.off_Z, g + y.off_ls, g + y.off_var, y.kdot));
+      HIPCHK(rbf_kuu_bwd(ctx->st, Sm, y.Kuu, y.Euu, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
+                         g + y.off_Z, g + y.off_ls, g + y.off_var, y.off_white >= 0 ? P(ctx, y.off_white) : nullptr));
+    }
+    if (y.off_white >= 0) HIPCHK(white_grad(ctx->st, Sm, M, Mp, acc + y.acc_dvar, g + y.off_white));
     HIPCHK(unpack_q_grads(ctx->st, y.dLq, y.dqmu_p, M, Mp, D, g + y.off_qsqrt, g + y.off_qmu));
   }
   }

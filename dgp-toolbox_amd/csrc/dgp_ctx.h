@@ -34,7 +34,9 @@ namespace {
 struct Layer {
   dgp_layer_desc d;
   int Mp;
-  long off_Z, off_var, off_ls, off_qmu, off_qsqrt;   // offsets in the flat parameter vector
+  long off_Z, off_var, off_ls, off_qmu, off_qsqrt;   // offsets in the flat parameter vector (DGP_KERNEL_MF: its 7
+                                                     // parameters start at off_var)
+  long off_white = -1;                               // white.variance when the kernel carries a White term
   double *meanW = nullptr, *meanb = nullptr;
   double *Kuu, *Lu, *Linv, *Lq, *qmu_p, *Wcat, *u;   // derived small matrices (padded to Mp)
   double *Scat;                                      // [D*Mp x Mp] (backward only): W_d^T stacked when t_d is kept from the
@@ -378,7 +380,7 @@ size_t carve(dgp_ctx* ctx, char* base, long Nc, int S, bool train) {
     if (train) { y.mbar = take(Pm * D); y.vbar = take(Pm * D); }
     else { y.mbar = y.vbar = nullptr; }
     y.Tt = (train && ctx->store_t) ? take(Pm * D * y.Mp) : nullptr;
-    y.Et = (train && y.d.kernel_kind != DGP_KERNEL_RBF) ? take(Pm * y.Mp) : nullptr;
+    y.Et = (train && (y.d.kernel_kind == DGP_KERNEL_MATERN32 || y.d.kernel_kind == DGP_KERNEL_MATERN52)) ? take(Pm * y.Mp) : nullptr;
   }
   if (train) {
     ctx->Cbar = take(Pmax_Mp); ctx->Kbar = take(Pmax_Mp); ctx->Gt = take(Pmax_Mp); ctx->xbar = take(xb_max);
@@ -429,8 +431,12 @@ int prep(dgp_ctx* ctx, bool train = false) {
     const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
     const long MM = (long)Mp * Mp;
     HIPCHK(pack_q(ctx->st, P(ctx, y.off_qsqrt), P(ctx, y.off_qmu), M, Mp, D, y.Lq, y.qmu_p));
-    HIPCHK(rbf_kuu(ctx->st, y.d.kernel_kind, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din, y.Kuu,
-                   train ? y.Euu : nullptr));
+    if (y.d.kernel_kind == DGP_KERNEL_MF)
+      HIPCHK(mf_kuu(ctx->st, P(ctx, y.off_Z), P(ctx, y.off_var), M, Mp, Din, y.Kuu));
+    else
+      HIPCHK(rbf_kuu(ctx->st, y.d.kernel_kind, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din, y.Kuu,
+                     train ? y.Euu : nullptr));
+    if (y.off_white >= 0) HIPCHK(add_diag_dev(ctx->st, y.Kuu, M, Mp, P(ctx, y.off_white)));
     HIPCHK(copy_mat(ctx->st, y.Kuu, y.Lu, MM));
     HIPCHK(potrf_inv(ctx->st, y.Lu, y.Linv, ctx->sm[9], Mp, 1, ctx->info));
     if (y.d.white) {
@@ -480,8 +486,11 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
     const int nplane = Mp / 32;
     {
       ProfScope ps(ctx, 1, 0, (double)Pl * (Mp + Din) * 8);
-      HIPCHK(rbf_kuf(ctx->st, y.d.kernel_kind, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
-                     y.Kt, y.Et));
+      if (y.d.kernel_kind == DGP_KERNEL_MF)
+        HIPCHK(mf_kuf(ctx->st, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), M, Mp, Din, y.Kt));
+      else
+        HIPCHK(rbf_kuf(ctx->st, y.d.kernel_kind, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
+                       y.Kt, y.Et));
     }
     const double tri1 = (double)Pl * Mp * (Mp + 1.0);   // 2 * M(M+1)/2 flops per point
     {  // c = Lu^-1 k  and |c|^2 partials
@@ -499,7 +508,8 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
       ProfScope ps(ctx, 1, 0, (double)Pl * nplane * 8 * (1 + D));
       HIPCHK(finalize_layer(ctx->st, y.cnp, y.tnp, nplane, Pm, y.mean0, Xin, row0, Pl, Nc, S, dedup ? 1 : 0, Din, D,
                             P(ctx, y.off_var), y.d.mean_kind, y.meanW, y.meanb,
-                            zsrc_of(ctx, l, use_zs, seed, n_goff, Ntot), n0, y.mean, y.var, y.F));
+                            zsrc_of(ctx, l, use_zs, seed, n_goff, Ntot), n0, y.mean, y.var, y.F, y.d.kernel_kind,
+                            y.off_white >= 0 ? P(ctx, y.off_white) : nullptr));
     }
   }
   return DGP_OK;
@@ -546,7 +556,9 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     {
       GemmArgs a = mk(Pm, Mp, Mp, ctx->Cbar, Mp, y.Linv, Mp, ctx->Kbar, Mp);
       a.tri = TRI_B_LOWER; a.triblk = Mp;
-      a.emul = y.Et ? y.Et : y.Kt; a.C2 = ctx->Gt;          // g = dK .* e (e = -2 dk/dr2; = k for the squared exponential)
+      if (y.d.kernel_kind != DGP_KERNEL_MF) {
+        a.emul = y.Et ? y.Et : y.Kt; a.C2 = ctx->Gt;        // g = dK .* e (e = -2 dk/dr2; = k for the squared exponential)
+      }
       RET(GX(ctx, 0, GEMM_NN, a, tri1, (double)Pl * Mp * 32));
     }
     // reductions over the chunk's points (accumulate into the all-reduce buffer)
@@ -568,7 +580,17 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
     }
     }
-    {  // RBF backward through Kuf: two skinny contractions of g with [Z | 1] and [X | 1]
+    if (y.d.kernel_kind == DGP_KERNEL_MF) {   // non-stationary kernel: direct pair reductions of dK (mfkern.hip)
+      ProfScope ps(ctx, 1, 0, (double)Pl * Mp * 16);
+      if (l > 0 || o.xgrad0)
+        HIPCHK(mf_kuf_bwd_x(ctx->st, ctx->Kbar, Xin, row0, Pl, P(ctx, y.off_Z), P(ctx, y.off_var), y.d.M, Mp, Din, y.vbar, D,
+                            ctx->xbar));
+      if (o.params) {
+        HIPCHK(mf_kuf_bwd_p(ctx->st, ctx->Kbar, Xin, row0, Pl, P(ctx, y.off_Z), P(ctx, y.off_var), y.d.M, Mp, Din,
+                            acc + y.acc_GX, acc + y.acc_x2));
+        HIPCHK(mf_kdiag_bwd(ctx->st, y.vbar, Xin, row0, Pl, Din, D, P(ctx, y.off_var), acc + y.acc_x2));
+      }
+    } else {  // RBF backward through Kuf: two skinny contractions of g with [Z | 1] and [X | 1]
       const int w1 = Din + 1;
       {
         ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 16);

@@ -57,7 +57,7 @@ hipError_t phi_tril_halfdiag(hipStream_t st, double* T, int Mp, int batch);
 hipError_t rbf_kuu_bwd(hipStream_t st, const double* S /* unsymmetrised dKuu */, const double* Kuu,
                        const double* Euu /* null: squared exponential, e = k */, const double* Z,
                        const double* var, const double* ls, int M, int Mp, int Din, double* dZ, double* dls,
-                       double* dvar);
+                       double* dvar, const double* white = nullptr /* White variance on Kuu's diagonal, if any */);
 hipError_t unpack_q_grads(hipStream_t st, const double* dLq, const double* dqmu_p, int M, int Mp, int D,
                           double* g_q_sqrt, double* g_q_mu);
 hipError_t symmetrize_axpy(hipStream_t st, const double* Gm, const double* Pinv, double two_gamma, double* out,
@@ -107,7 +107,8 @@ hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, 
                           long pstride /* rows per partial plane */, const double* mean0,
                           const double* Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
                           const double* kvar, int mean_kind, const double* meanW, const double* meanb, ZSource zsrc,
-                          long n_chunk0, double* mean, double* var, double* F);
+                          long n_chunk0, double* mean, double* var, double* F, int kernel_kind = 0,
+                          const double* white = nullptr);   // kvar: kern.variance, or the 7 parameters of DGP_KERNEL_MF
 // Gaussian variational expectations (gpflow Gaussian, via utils.py:89-93) + seeds of the backward pass
 hipError_t gauss_lik(hipStream_t st, const double* mean, const double* var, const double* Y, long y_row0, long Nc,
                      int S, int dedup, int Dy, const double* lik_var, double* acc_elbo, double* acc_dlik,
@@ -117,7 +118,8 @@ hipError_t fold_sample_grad(hipStream_t st, const double* Fbar, const double* va
                             ZSource zsrc, long n_chunk0, double* mbar, double* vbar, double* acc_dkvar);
 // seeds of a vector-Jacobian product through the last layer: cotangents of (F, Fmean, Fvar), each [S, Ntot, D] or null
 hipError_t vjp_seed(hipStream_t st, const double* fbar, const double* meanbar, const double* varbar, const double* var,
-                    long Nc, int S, int dedup, int D, ZSource zsrc, long Ntot, long n_chunk0, double* mbar, double* vbar);
+                    long Nc, int S, int dedup, int D, ZSource zsrc, long Ntot, long n_chunk0, double* mbar, double* vbar,
+                    double* acc_dkvar = nullptr);
 hipError_t cbar_fix(hipStream_t st, double* Cbar, const double* mbar, const double* u, long P, int Mp, int D);
 hipError_t make_x1(hipStream_t st, const double* Xin, long x_row0, long P, int Din, double* X1);     // [X | 1]
 hipError_t xbar_finish(hipStream_t st, const double* R1, const double* X1, long P, const double* ls, int Din, int D,
@@ -135,6 +137,23 @@ hipError_t fc_sample(hipStream_t st, const double* L /* [D][Np][Np] */, const do
                      ZSource zsrc, int s, double* F);
 hipError_t launch_normals(hipStream_t st, ZSource z, int S, long N, int D, double* out);
 hipError_t launch_mfma_peak(hipStream_t st, int blocks, int iters, double* sink);
+
+// ---------------------------------------------------------------- multi-fidelity kernel, White variance (mfkern.hip)
+// hyp = [corr.variance, corr.lengthscales, prev.variance, prev.lengthscales, linear.variance, in.variance, in.lengthscales]
+hipError_t mf_kuu(hipStream_t st, const double* Z, const double* hyp, int M, int Mp, int Din, double* Kuu);
+hipError_t mf_kuf(hipStream_t st, const double* Xin, long P, long x_row0, const double* Z, const double* hyp, int M, int Mp,
+                  int Din, double* Kt);
+hipError_t mf_kuf_bwd_x(hipStream_t st, const double* Kbar, const double* Xin, long x_row0, long P, const double* Z,
+                        const double* hyp, int M, int Mp, int Din, const double* vbar, int D, double* xbar);
+hipError_t mf_kuf_bwd_p(hipStream_t st, const double* Kbar, const double* Xin, long x_row0, long P, const double* Z,
+                        const double* hyp, int M, int Mp, int Din, double* accZ, double* accH);
+hipError_t mf_kdiag_bwd(hipStream_t st, const double* vbar, const double* Xin, long x_row0, long P, int Din, int D,
+                        const double* hyp, double* accH);
+hipError_t mf_collect(hipStream_t st, const double* accZ, const double* accH, int M, int Din, double* gZ, double* gH);
+hipError_t mf_kuu_bwd(hipStream_t st, const double* S, const double* Z, const double* hyp, int M, int Mp, int Din, double* gZ,
+                      double* gH);
+hipError_t add_diag_dev(hipStream_t st, double* A, int M, int Mp, const double* v);          // A[i][i] += v[0], i < M
+hipError_t white_grad(hipStream_t st, const double* S, int M, int Mp, const double* vsum, double* out);
 
 // ---------------------------------------------------------------- optimiser kernels (optim.hip)
 enum Transform : int { TR_IDENTITY = 0, TR_SOFTPLUS = 1, TR_SOFTPLUS_SHIFT = 2, TR_TRIL = 3 };

@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void finalize_layer_kernel(
     const double* __restrict__ mean0,
     const double* __restrict__ Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
     const double* __restrict__ kvar, int mean_kind, const double* __restrict__ meanW, const double* __restrict__ meanb,
-    ZSource zsrc, long n_chunk0, double* __restrict__ mean, double* __restrict__ var, double* __restrict__ F) {
+    ZSource zsrc, long n_chunk0, double* __restrict__ mean, double* __restrict__ var, double* __restrict__ F,
+    int kernel_kind, const double* __restrict__ white) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= P * D) return;
   const int d = (int)(idx / P);
@@ -156,7 +157,13 @@ __global__ __launch_bounds__(256) void finalize_layer_kernel(
     for (int j = 0; j < Din; ++j) mf += x[j] * meanW[(long)j * D + d];
     mf += meanb[d];
   }
-  const double mv = mean0[p * D + d] + mf, vv = kvar[0] - cn + tn;
+  double kd = kvar[0];
+  if (kernel_kind == 3) {             // DGP_KERNEL_MF: K_diag = vC (vP + vL f^2) + vI, f = last input column
+    const double f = x[Din - 1];
+    kd = kvar[0] * (kvar[2] + kvar[4] * f * f) + kvar[5];
+  }
+  if (white) kd += white[0];
+  const double mv = mean0[p * D + d] + mf, vv = kd - cn + tn;
   mean[p * D + d] = mv;
   var[p * D + d] = vv;
   if (F) {
@@ -175,11 +182,12 @@ hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, 
                           const double* mean0,
                           const double* Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
                           const double* kvar, int mean_kind, const double* meanW, const double* meanb, ZSource zsrc,
-                          long n_chunk0, double* mean, double* var, double* F) {
+                          long n_chunk0, double* mean, double* var, double* F, int kernel_kind, const double* white) {
   const long n = P * D;
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(finalize_layer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cnp, tnp, nplane, pstride, mean0, Xin,
-                     x_row0, P, Nc, S, dedup, Din, D, kvar, mean_kind, meanW, meanb, zsrc, n_chunk0, mean, var, F);
+                     x_row0, P, Nc, S, dedup, Din, D, kvar, mean_kind, meanW, meanb, zsrc, n_chunk0, mean, var, F, kernel_kind,
+                     white);
   LAUNCH_CHECK();
 }
 
@@ -285,7 +293,10 @@ hipError_t fold_sample_grad(hipStream_t st, const double* Fbar, const double* va
 __global__ __launch_bounds__(256) void vjp_seed_kernel(const double* __restrict__ fbar, const double* __restrict__ meanbar,
                                                        const double* __restrict__ varbar, const double* __restrict__ var,
                                                        long Nc, int S, int dedup, int D, ZSource zsrc, long Ntot,
-                                                       long n_chunk0, double* __restrict__ mbar, double* __restrict__ vbar) {
+                                                       long n_chunk0, double* __restrict__ mbar, double* __restrict__ vbar,
+                                                       double* __restrict__ acc_dkvar) {
+  __shared__ double sh[4];
+  double dk = 0.0;
   const long P = dedup ? Nc : (long)S * Nc;
   const long total = P * D;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -307,16 +318,19 @@ __global__ __launch_bounds__(256) void vjp_seed_kernel(const double* __restrict_
     }
     mbar[idx] = mb;
     vbar[idx] = vb;
+    dk += vb;
   }
+  if (acc_dkvar) block_atomic_add(dk, acc_dkvar, sh);
 }
 hipError_t vjp_seed(hipStream_t st, const double* fbar, const double* meanbar, const double* varbar, const double* var,
-                    long Nc, int S, int dedup, int D, ZSource zsrc, long Ntot, long n_chunk0, double* mbar, double* vbar) {
+                    long Nc, int S, int dedup, int D, ZSource zsrc, long Ntot, long n_chunk0, double* mbar, double* vbar,
+                    double* acc_dkvar) {
   const long total = (dedup ? Nc : (long)S * Nc) * D;
   if (total == 0) return hipSuccess;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(vjp_seed_kernel, dim3((unsigned)blocks), dim3(256), 0, st, fbar, meanbar, varbar, var, Nc, S, dedup, D,
-                     zsrc, Ntot, n_chunk0, mbar, vbar);
+                     zsrc, Ntot, n_chunk0, mbar, vbar, acc_dkvar);
   LAUNCH_CHECK();
 }
 

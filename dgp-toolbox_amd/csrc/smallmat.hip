@@ -511,13 +511,13 @@ __global__ __launch_bounds__(64) void rbf_kuu_bwd_kernel(const double* __restric
                                                          const double* __restrict__ Z, const double* __restrict__ var,
                                                          const double* __restrict__ ls, int M, int Mp, int Din,
                                                          double* __restrict__ dZ, double* __restrict__ dls,
-                                                         double* __restrict__ dvar) {
+                                                         double* __restrict__ dvar, const double* __restrict__ white) {
   // one wave per (inducing point m, input dimension j): lanes stride over n, so rows of Kuu and S are read coalesced
   const int m = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
   const double zm = Z[(long)m * Din + j], l = ls[j];
   double zacc = 0.0, lacc = 0.0, vacc = 0.0;
   for (int n = lane; n < M; n += 64) {
-    const double k0 = Kuu[(long)m * Mp + n] - (m == n ? kJitter : 0.0);
+    const double k0 = Kuu[(long)m * Mp + n] - (m == n ? kJitter + (white ? white[0] : 0.0) : 0.0);
     const double sym = 0.5 * (S[(long)m * Mp + n] + S[(long)n * Mp + m]);
     const double h = sym * (Euu ? Euu[(long)m * Mp + n] : k0);       // dKuu .* e: inputs and lengthscales
     const double dl = zm - Z[(long)n * Din + j];
@@ -537,8 +537,10 @@ __global__ __launch_bounds__(64) void rbf_kuu_bwd_kernel(const double* __restric
   }
 }
 hipError_t rbf_kuu_bwd(hipStream_t st, const double* S, const double* Kuu, const double* Euu, const double* Z,
-                       const double* var, const double* ls, int M, int Mp, int Din, double* dZ, double* dls, double* dvar) {
-  hipLaunchKernelGGL(rbf_kuu_bwd_kernel, dim3(M, Din), dim3(64), 0, st, S, Kuu, Euu, Z, var, ls, M, Mp, Din, dZ, dls, dvar);
+                       const double* var, const double* ls, int M, int Mp, int Din, double* dZ, double* dls, double* dvar,
+                       const double* white) {
+  hipLaunchKernelGGL(rbf_kuu_bwd_kernel, dim3(M, Din), dim3(64), 0, st, S, Kuu, Euu, Z, var, ls, M, Mp, Din, dZ, dls, dvar,
+                     white);
   LAUNCH_CHECK();
 }
 

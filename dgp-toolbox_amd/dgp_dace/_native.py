@@ -20,7 +20,7 @@ DGP_OK, ERR_INVALID, ERR_HIP, ERR_NOT_PD, ERR_NO_DEVICE, ERR_NONFINITE = 0, -1, 
 SYMBOLS = [
     "dgp_create", "dgp_destroy", "dgp_last_error", "dgp_sync", "dgp_device_info", "dgp_model_set", "dgp_param_count",
     "dgp_params_get", "dgp_params_set", "dgp_data_set", "dgp_set_workspace_limit", "dgp_elbo", "dgp_propagate",
-    "dgp_propagate_vjp", "dgp_propagate_full_cov", "dgp_gpr_lml", "dgp_gpr_predict", "dgp_gpr_predict_vjp",
+    "dgp_propagate_vjp", "dgp_vjp_accumulate", "dgp_propagate_full_cov", "dgp_gpr_lml", "dgp_gpr_predict", "dgp_gpr_predict_vjp",
     "dgp_grad_partial", "dgp_acc_info", "dgp_acc_bind", "dgp_grad_finish", "dgp_grad_get", "dgp_last_elbo",
     "dgp_adam_reset", "dgp_adam_step", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_dev_gemm",
     "dgp_dev_chol", "dgp_dev_trinv", "dgp_dev_normals", "dgp_dev_mfma_peak",
@@ -43,7 +43,7 @@ class NotPositiveDefinite(NativeError):
 
 class LayerDesc(C.Structure):
     _fields_ = [("D_in", C.c_int32), ("D_out", C.c_int32), ("M", C.c_int32), ("white", C.c_int32),
-                ("kernel_kind", C.c_int32), ("mean_kind", C.c_int32)]
+                ("kernel_kind", C.c_int32), ("mean_kind", C.c_int32), ("kernel_white", C.c_int32)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -77,6 +77,7 @@ def load():
         "dgp_elbo": (C.c_int, [vp, i32, u64, _dpp, _dp, _dp]),
         "dgp_propagate": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dpp, _dpp, _dpp, i32]),
         "dgp_propagate_vjp": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dp, _dp, _dp, _dp]),
+        "dgp_vjp_accumulate": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dp, _dp, _dp, _dp, i32]),
         "dgp_propagate_full_cov": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dpp, _dpp, _dpp]),
         "dgp_gpr_lml": (C.c_int, [vp, i32, _dp, _dp, i64, i32, i32, C.c_double, _dp, C.c_double, _dp, _dp]),
         "dgp_gpr_predict": (C.c_int, [vp, i32, _dp, _dp, i64, i32, i32, C.c_double, _dp, C.c_double, _dp, i64, i32, _dp, _dp]),
@@ -247,8 +248,11 @@ class Context:
                                                 _ptr(mb), _ptr(vb), _ptr(out)))
         return out
 
-    def propagate_vjp(self, Xnew, S, seed=0, zs=None, f_bar=None, mean_bar=None, var_bar=None):
-        """d(sum of cotangent * last-layer output)/dXnew, [Nn, D_in] (dgp_propagate_vjp)."""
+    def propagate_vjp(self, Xnew, S, seed=0, zs=None, f_bar=None, mean_bar=None, var_bar=None, accumulate=None):
+        """d(sum of cotangent * last-layer output)/dXnew, [Nn, D_in] (dgp_propagate_vjp).
+
+        accumulate: None = inputs only; "reset" / "add" = also add the parameter sums of this call to the gradient
+        accumulator, cleared first or not (dgp_vjp_accumulate; finish with grad_finish / grad_get)."""
         Xnew = _c(Xnew)
         Nn = Xnew.shape[0]
         zp, keep = self._zs(zs)
@@ -263,8 +267,13 @@ class Context:
                 raise ValueError(f"cotangent of shape {b.shape}, expected {shape}")
             bars.append(b)
         out = np.empty((Nn, Xnew.shape[1]))
-        self._chk(self._lib.dgp_propagate_vjp(self._h, _ptr(Xnew), Nn, int(S), int(seed) & (2 ** 64 - 1), zp,
-                                              *[_ptr(b) if b is not None else None for b in bars], _ptr(out)))
+        if accumulate is None:
+            self._chk(self._lib.dgp_propagate_vjp(self._h, _ptr(Xnew), Nn, int(S), int(seed) & (2 ** 64 - 1), zp,
+                                                  *[_ptr(b) if b is not None else None for b in bars], _ptr(out)))
+        else:
+            self._chk(self._lib.dgp_vjp_accumulate(self._h, _ptr(Xnew), Nn, int(S), int(seed) & (2 ** 64 - 1), zp,
+                                                   *[_ptr(b) if b is not None else None for b in bars], _ptr(out),
+                                                   1 if accumulate == "reset" else 0))
         return out
 
     # ---- backward + optimisers --------------------------------------------------------------

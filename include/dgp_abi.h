@@ -35,7 +35,13 @@ enum dgp_status {
 enum dgp_kernel_kind {      /* gpflow stationary kernels with ARD lengthscales (SO_BO.py:192-197,239-244) */
   DGP_KERNEL_RBF = 0,       /* SquaredExponential / RBF */
   DGP_KERNEL_MATERN32 = 1,
-  DGP_KERNEL_MATERN52 = 2
+  DGP_KERNEL_MATERN52 = 2,
+  /* the multi-fidelity layer kernel of MF_DGP_EM.py:346-352 on inputs [x (D_in-1 columns), f (last column)]:
+   *   k_corr(x,x') * (k_prev(f,f') + Linear(f,f')) + k_in(x,x'),  k_* = SquaredExponential with ONE lengthscale each.
+   * Its 7 parameters replace `variance, lengthscales` in flat_params, in this order:
+   *   corr.variance, corr.lengthscales, prev.variance, prev.lengthscales, linear.variance (0 = `add_linear=False`),
+   *   in.variance, in.lengthscales.   Zero mean function only.                                                   */
+  DGP_KERNEL_MF = 3
 };
 enum dgp_mean_kind { DGP_MEAN_ZERO = 0, DGP_MEAN_IDENTITY = 1, DGP_MEAN_LINEAR = 2 };
 
@@ -45,6 +51,8 @@ typedef struct dgp_layer_desc {
   int32_t white;        /* layers.py:181 `white=`                        */
   int32_t kernel_kind;  /* dgp_kernel_kind                                */
   int32_t mean_kind;    /* dgp_mean_kind (layer_initializations.py:41-55) */
+  int32_t kernel_white; /* 1: the kernel is `... + gpflow.kernels.White(variance)` (MF_DGP_EM.py:364-367): one more
+                           parameter, white.variance, follows the kernel parameters; it enters Kuu and K_diag only */
 } dgp_layer_desc;
 
 /* ---- lifetime --------------------------------------------------------------------------------- */
@@ -58,8 +66,9 @@ int dgp_device_info(dgp_ctx* ctx, char* name_out, int name_len, int* cu_count, i
 /* ---- model: replaces DGP.__init__ / init_layers_linear / SVGP_Layer.__init__ state
  *      (dgp.py:245-254, layer_initializations.py:24-68, layers.py:181-224).
  * flat_params packs the *constrained* values, per layer in this order:
- *   Z[M*D_in], kern.variance[1], kern.lengthscales[D_in], q_mu[M*D_out], q_sqrt[D_out*M*M] (dense,
- *   lower-triangular), and after the last layer likelihood.variance[1].
+ *   Z[M*D_in], kern.variance[1], kern.lengthscales[D_in] (DGP_KERNEL_MF: its 7 parameters), white.variance[1] when
+ *   kernel_white, q_mu[M*D_out], q_sqrt[D_out*M*M] (dense, lower-triangular), and after the last layer
+ *   likelihood.variance[1].
  * mean_params packs, for every layer with DGP_MEAN_LINEAR, A[D_in*D_out] then b[D_out].          */
 int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, const double* flat_params,
                   int64_t n_params, const double* mean_params, int64_t n_mean_params);
@@ -100,6 +109,17 @@ int dgp_propagate_full_cov(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t
  * utils.py:40-41).  xbar_out: host [Nn, D_in] = sum over outputs of cotangent * d output / d Xnew.            */
 int dgp_propagate_vjp(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
                       const double* f_bar, const double* mean_bar, const double* var_bar, double* xbar_out);
+
+/* dgp_propagate_vjp WITH the parameter sums: the partial sums of d/d(parameters) of  sum(cotangent * output)  are
+ * ADDED to the gradient accumulator (cleared first when `reset` != 0) and the same x-gradient is returned.  Several
+ * calls may precede one dgp_grad_finish, which then yields  sum over the calls of the data-side gradients  minus the
+ * gradient of the layer KLs, once (the ELBO it reports is then -sum KL): this is how a model that evaluates one layer
+ * at several input sets inside one bound is differentiated - the multi-fidelity graph of MF_DGP_EM.py:262-301, where
+ * `tape.gradient` (MF_DGP_EM.py:460-464) reaches layers[0] through X_lf, through the mapped high-fidelity inputs and
+ * through the Z_right inputs.  xbar_out may be NULL.                                                               */
+int dgp_vjp_accumulate(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed, const double* const* zs,
+                       const double* f_bar, const double* mean_bar, const double* var_bar, double* xbar_out,
+                       int32_t reset);
 
 /* ---- exact GP regression: replaces gpflow.models.GPR as SO_BO builds it for num_layers == 0 (SO_BO.py:187-200,
  *      training :252-256, prediction through Infill_criteria.py:28-35).  Stateless (needs only dgp_create), N <= 1024.
