@@ -94,15 +94,61 @@ def _val(p):
     return np.asarray(p.numpy() if hasattr(p, "numpy") else p, dtype=np.float64)
 
 
-class SquaredExponential:
+class _KernelOps:
+    """`k1 + k2` / `k1 * k2` as gpflow builds Sum / Product kernels (MF_DGP_EM.py:350-352,367)."""
+
+    def __add__(self, other):
+        return Sum([self, other])
+
+    def __mul__(self, other):
+        return Product([self, other])
+
+
+class _Combination(_KernelOps):
+    def __init__(self, kernels):
+        self.kernels = []
+        for k in kernels:                      # gpflow flattens nested combinations of the same type
+            self.kernels.extend(k.kernels if type(k) is type(self) else [k])
+
+
+class Sum(_Combination):
+    kind = "sum"
+
+
+class Product(_Combination):
+    kind = "product"
+
+
+class SquaredExponential(_KernelOps):
     """gpflow.kernels.SquaredExponential: K = variance * exp(-0.5 * |x/l - x'/l|^2), K_diag = variance."""
 
     kind = "rbf"
 
-    def __init__(self, variance=1.0, lengthscales=1.0, **_):
+    def __init__(self, variance=1.0, lengthscales=1.0, active_dims=None, **_):
         self.variance = Parameter(np.asarray(variance, dtype=np.float64).reshape(()), "variance", "softplus")
         self.lengthscales = Parameter(np.atleast_1d(np.asarray(lengthscales, dtype=np.float64)), "lengthscales",
                                       "softplus")
+        self.active_dims = None if active_dims is None else list(active_dims)
+
+
+class LinearKernel(_KernelOps):
+    """gpflow.kernels.Linear: K = variance * x x'^T on its active dimension(s)."""
+
+    kind = "linear"
+
+    def __init__(self, variance=1.0, active_dims=None, **_):
+        self.variance = Parameter(np.asarray(variance, dtype=np.float64).reshape(()), "variance", "softplus")
+        self.active_dims = None if active_dims is None else list(active_dims)
+
+
+class White(_KernelOps):
+    """gpflow.kernels.White: variance * I on K(X) and K_diag, zero cross-covariance."""
+
+    kind = "white"
+
+    def __init__(self, variance=1.0, active_dims=None, **_):
+        self.variance = Parameter(np.asarray(variance, dtype=np.float64).reshape(()), "variance", "softplus")
+        self.active_dims = None if active_dims is None else list(active_dims)
 
 
 RBF = SquaredExponential
@@ -171,6 +217,8 @@ class Linear:
 class kernels:           # `from dgp_dace.gpflow_compat import kernels; kernels.RBF(...)`
     SquaredExponential = SquaredExponential
     RBF = SquaredExponential
+    Matern32, Matern52 = Matern32, Matern52
+    Linear, White, Sum, Product = LinearKernel, White, Sum, Product
 
 
 class likelihoods:

@@ -94,3 +94,97 @@ def test_single_layer_with_mf_kernel_and_white_variance(kind, white, D_out):
     ctx.grad_finish()
     g0 = ctx.grad_get()          # - d KL only
     np.testing.assert_allclose(g2 - g0, 2.0 * (g - g0), rtol=1e-9, atol=1e-9)
+
+
+def _mf_problem(rng, n_fid):
+    dims = [2, 3, 2][:n_fid]
+    Ns = [14, 9, 6][:n_fid]
+    X = [rng.uniform(0, 1, (Ns[i], dims[i])) for i in range(n_fid)]
+    Y = [np.sin(3 * x.sum(1, keepdims=True)) + 0.1 * i for i, x in enumerate(X)]
+    X_red = [rng.uniform(0, 1, (Ns[i + 1], dims[0])) for i in range(n_fid - 1)]
+    return X, Y, X_red
+
+
+def _pair_models(rng, X, Y, X_red, S):
+    """The product model and the oracle parameter set in the same (non-trivial) state."""
+    import torch
+    import mf_dgp_em_oracle as mo
+    from dgp_dace.models.MF_DGP_EM import MultiFidelityDeepGP_EM
+    mf = MultiFidelityDeepGP_EM(X, Y, X_red, seed=1)
+    m = mf.model
+    m.num_samples = S
+    P = mo.make_params(X, mf.Z, mf.W)
+    names = {}
+
+    def tie(param, leaf_name, value=None):
+        v = np.asarray(param._value if value is None else value, dtype=np.float64)
+        param._value = v.copy()
+        with torch.no_grad():
+            mo.leaves(P)[leaf_name].copy_(torch.as_tensor(v).reshape(mo.leaves(P)[leaf_name].shape))
+        names[id(param)] = leaf_name
+
+    for group, layers in (("layers", m.layers), ("layers_red", m.layers_red)):
+        for i, lay in enumerate(layers):
+            M, D = lay.num_inducing, lay.num_outputs
+            tie(lay.feature.left(), f"{group}.{i}.Z")
+            tie(lay.q_mu, f"{group}.{i}.q_mu", rng.standard_normal((M, D)) * 0.5)
+            tie(lay.q_sqrt, f"{group}.{i}.q_sqrt", np.tril(rng.standard_normal((D, M, M)) * 0.05) + 0.4 * np.eye(M)[None])
+            if lay.kind == 0:
+                tie(lay._kpars[0], f"{group}.{i}.kern.variance", rng.uniform(0.7, 1.3))
+                tie(lay._kpars[1], f"{group}.{i}.kern.lengthscales", rng.uniform(0.7, 1.3, lay.input_dim))
+            else:
+                for p, nm in zip(lay._kpars, ["corr_variance", "corr_lengthscales", "prev_variance", "prev_lengthscales",
+                                              "lin_variance", "in_variance", "in_lengthscales"]):
+                    tie(p, f"{group}.{i}.kern.{nm}", rng.uniform(0.7, 1.3, p._value.shape))
+            if lay._white is not None:
+                tie(lay._white, f"{group}.{i}.kern.white_variance", 0.05)
+    tie(m.likelihood.likelihood.variance, "lik_variance", 0.3)
+    tie(m.likelihood_projection.likelihood.variance, "proj_variance", 0.2)
+    return mf, P, names
+
+
+@pytest.mark.parametrize("n_fid", [2, 3])
+def test_mf_dgp_em_bound_and_gradient_match_the_restatement(n_fid):
+    import mf_dgp_em_oracle as mo
+    rng = np.random.default_rng(11 + n_fid)
+    X, Y, X_red = _mf_problem(rng, n_fid)
+    S = 3
+    mf, P, names = _pair_models(rng, X, Y, X_red, S)
+    normals = mo.draw_normals(rng, X, P, S)
+    ref, parts, g_ref = mo.elbo_and_grads(P, X, Y, X_red, normals, S)
+    val, grads = mf.model.ELBO_and_grad((X, Y, X_red), normals=normals)
+    for k, got in (("L", mf.model.L), ("L_red", mf.model.L_red), ("KL", mf.model.KL), ("KL_red", mf.model.KL_red)):
+        assert abs(got - parts[k]) <= 1e-8 * max(1.0, abs(parts[k])), (k, got, parts[k])
+    assert abs(val - ref) <= 1e-8 * max(1.0, abs(ref))
+    assert abs(mf.model.ELBO((X, Y, X_red), normals=normals) - ref) <= 1e-8 * max(1.0, abs(ref))
+    assert set(names) == {id(p) for p in mf.model.parameters()}
+    for p in mf.model.parameters():
+        want = g_ref[names[id(p)]].reshape(p._value.shape)
+        got = np.asarray(grads[id(p)]).reshape(p._value.shape)
+        scale = max(1.0, np.abs(want).max())
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7 * scale, err_msg=names[id(p)])
+
+
+def test_mf_dgp_em_training_phases_and_prediction(capsys):
+    """The three training parts of optimize_adam / optimize_nat_adam (MF_DGP_EM.py:429-578) run on the device path,
+    the bound improves and the high-fidelity prediction beats the data's spread on held-out points."""
+    from dgp_dace.models.MF_DGP_EM import MultiFidelityDeepGP_EM
+    rng = np.random.default_rng(3)
+    lf = lambda x: np.sin(6 * x[:, :1]) + 0.3 * x[:, 1:2]
+    hf = lambda x: 1.5 * lf(np.concatenate([x[:, :1], 0.5 * np.ones((len(x), 1))], 1)) + 0.2 * x[:, :1]
+    X0 = rng.uniform(0, 1, (30, 2)); X1 = rng.uniform(0, 1, (10, 1))
+    X = [X0, X1]
+    Y = [lf(X0), hf(X1)]
+    X_red = [np.concatenate([X1, 0.5 * np.ones((10, 1))], 1)]
+    for method in ("optimize_adam", "optimize_nat_adam"):
+        mf = MultiFidelityDeepGP_EM(X, Y, X_red, seed=0)
+        mf.model.num_samples = 10
+        getattr(mf, method)(iterations1=15, iterations2=10, iterations3=15, messages=5)
+        out = capsys.readouterr().out
+        trace = [float(l.split(":")[1]) for l in out.splitlines() if l.startswith("ELBO")]
+        assert len(trace) == 3 + 2 + 3 and np.all(np.isfinite(trace))
+        assert trace[-1] > trace[0]
+        Xt = rng.uniform(0, 1, (20, 1))
+        mean, var = mf.predict(Xt)
+        assert mean.shape == (20, 1) and var.shape == (20, 1) and np.all(var > 0) and np.all(np.isfinite(mean))
+        assert np.sqrt(np.mean((mean - hf(Xt)) ** 2)) < np.std(Y[1])
