@@ -258,7 +258,7 @@ class DGP_Base:
         self.rng = np.random.default_rng(seed)
         self.L = self.KL = self.L_red = self.KL_red = 0.0
 
-    # ---- random draws of one ELBO evaluation (layout of oracle/mf_dgp_em_oracle.draw_normals) ----
+    # ---- random draws of one ELBO evaluation (one dict per evaluation; tests inject the same layout) ----
     def _draw_zright(self, n_zright=50):
         n, L, rng = self.num_layers, len(self.layers_red), self.rng
         out = [None]

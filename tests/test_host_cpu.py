@@ -327,3 +327,87 @@ def test_so_bo_host_logic_without_a_device():
             return [np.sum(x ** 2, 1, keepdims=True)]
     bo2 = SO_BO(Free(), DoE_size=6, model_Y_dic={'num_layers': 1, 'num_units': 2, 'kernels': 'rbf', 'num_samples': 4}, seed=3)
     assert bo2.X.shape == (6, 2) and bo2.C is None and np.isclose(bo2.Ymin[-1], bo2.Y.min())
+
+
+def test_mf_kernel_plans_and_no_cpu_fallback():
+    """The multi-fidelity mirror maps the reference's kernel expressions (MF_DGP_EM.py:341-367) onto the C-ABI kernel
+    kinds, refuses anything else, and needs the device as soon as a layer is evaluated."""
+    from dgp_dace.gpflow_compat import RBF, LinearKernel, White, Matern32
+    from dgp_dace.models import MF_DGP_EM as MF
+    k0 = RBF(active_dims=[0, 1], variance=1.0, lengthscales=[1.0, 1.0]) + White(variance=1e-6)
+    kind, pars, white = MF._kernel_plan(k0, 2)
+    assert kind == 0 and [p._value.size for p in pars] == [1, 2] and float(white._value) == 1e-6
+    kc, kp, kl, ki = RBF(active_dims=[0, 1]), RBF(active_dims=[2]), LinearKernel(active_dims=[2]), RBF(active_dims=[0, 1])
+    kind, pars, white = MF._kernel_plan(kc * (kp + kl) + ki, 3)
+    assert kind == 3 and white is None
+    assert [id(p) for p in pars] == [id(kc.variance), id(kc.lengthscales), id(kp.variance), id(kp.lengthscales),
+                                     id(kl.variance), id(ki.variance), id(ki.lengthscales)]
+    kind, pars, white = MF._kernel_plan(RBF(active_dims=[0]) * RBF(active_dims=[1]) + RBF(active_dims=[0]) + White(0.1), 2)
+    assert kind == 3 and pars[4] is None and float(white._value) == 0.1            # add_linear=False
+    for bad in (Matern32() + White(), RBF(active_dims=[1]) * RBF(active_dims=[0]) + RBF(active_dims=[0]),
+                RBF() + RBF()):
+        with pytest.raises(NotImplementedError):
+            MF._kernel_plan(bad, 2)
+    # host kernel used once for the prior initialisation of q_sqrt against the oracle's kernel
+    import torch
+    import mf_dgp_em_oracle as mo
+    rng = np.random.default_rng(0)
+    Z = rng.uniform(0, 1, (7, 3))
+    vals = list(rng.uniform(0.5, 1.5, 7))
+    k = {"type": "mf", "Dx": 2, "white_variance": mo._t(0.2)}
+    for nm, v in zip(["corr_variance", "corr_lengthscales", "prev_variance", "prev_lengthscales", "lin_variance",
+                      "in_variance", "in_lengthscales"], vals):
+        k[nm] = mo._t(v)
+    np.testing.assert_allclose(MF._kernel_matrix_host(3, vals, 0.2, Z), mo.kern_K(k, torch.as_tensor(Z)).detach().numpy(),
+                               rtol=1e-12, atol=1e-12)
+    if not torch.cuda.is_available():
+        from dgp_dace._native import NativeUnavailable
+        X = [rng.uniform(0, 1, (6, 2)), rng.uniform(0, 1, (4, 1))]
+        Y = [rng.standard_normal((6, 1)), rng.standard_normal((4, 1))]
+        with pytest.raises(NativeUnavailable):
+            MF.MultiFidelityDeepGP_EM(X, Y, [rng.uniform(0, 1, (4, 2))])
+    src = open(os.path.join(ROOT, "dgp-toolbox_amd", "dgp_dace", "models", "MF_DGP_EM.py")).read()
+    assert "oracle" not in src and "import torch" not in src
+
+
+def test_mf_oracle_autograd_against_finite_differences():
+    """The torch restatement of the MF-DGP-EM bound: autograd against central differences on a few leaves, and the
+    literal N_{f+1}/N_f scale of the projection term (MF_DGP_EM.py:292-294)."""
+    import torch
+    import mf_dgp_em_oracle as mo
+    rng = np.random.default_rng(0)
+    X = [rng.uniform(0, 1, (9, 2)), rng.uniform(0, 1, (5, 3))]
+    Y = [rng.standard_normal((9, 1)), rng.standard_normal((5, 1))]
+    X_red = [rng.uniform(0, 1, (5, 2))]
+    P = mo.make_params(X, [x.copy() for x in X], [X[-1].copy()])
+    with torch.no_grad():
+        for i, l in enumerate(P["layers"]):
+            l["q_mu"].copy_(torch.as_tensor(Y[i])); l["q_sqrt"].mul_(0.3)
+        P["layers"][0]["kern"]["white_variance"].fill_(0.05)
+    S = 3
+    nm = mo.draw_normals(rng, X, P, S)
+    val, parts, g = mo.elbo_and_grads(P, X, Y, X_red, nm, S)
+    assert abs(val - (parts["L"] + parts["L_red"] - parts["KL"] - parts["KL_red"])) < 1e-9 * abs(val)
+    lv = mo.leaves(P)
+    for name in ("layers.1.kern.lin_variance", "layers.1.Z", "layers_red.0.Z", "layers.0.kern.white_variance", "layers.0.q_sqrt"):
+        t = lv[name]
+        idx = tuple(0 for _ in t.shape)
+        h = 1e-6
+        with torch.no_grad(): t[idx] += h
+        vp = mo.elbo_and_grads(P, X, Y, X_red, nm, S)[0]
+        with torch.no_grad(): t[idx] -= 2 * h
+        vm = mo.elbo_and_grads(P, X, Y, X_red, nm, S)[0]
+        with torch.no_grad(): t[idx] += h
+        fd = (vp - vm) / (2 * h)
+        assert abs(fd - g[name][idx]) <= 1e-5 * max(1.0, abs(fd)), (name, fd, g[name][idx])
+    # doubling the high-fidelity set's size while halving nothing else doubles the scale factor only through N_1 / N_0
+    X2 = [X[0], np.concatenate([X[1], X[1]])]
+    P2 = mo.make_params(X2, [X[0].copy(), X[1].copy()], [X[1].copy()])
+    with torch.no_grad():
+        for a, b in zip(mo.leaves(P2).values(), mo.leaves(P).values()):
+            a.copy_(b)
+    nm2 = {"zright": nm["zright"], "zs": [nm["zs"][0], [np.concatenate([z, z], 1) for z in nm["zs"][1]]],
+           "ws": [nm["ws"][0], [np.concatenate([w, w], 1) for w in nm["ws"][1]]],
+           "ws_proj": [[np.concatenate([w, w], 1) for w in nm["ws_proj"][0]]]}
+    _, parts2, _ = mo.elbo_and_grads(P2, X2, [Y[0], np.concatenate([Y[1], Y[1]])], [np.concatenate([X_red[0], X_red[0]])], nm2, S)
+    assert abs(parts2["L_red"] - 4.0 * parts["L_red"]) <= 1e-9 * abs(parts["L_red"])      # 2x the points, 2x the scale
