@@ -63,6 +63,7 @@ struct GemmArgs {
   // TRI_OUT_LOWER launches: number of output tiles that survive the skip when the grid is COMPACT (only those
   // tiles are launched: early-exit workgroups were measured to cost as much as running ones); 0 = full grid
   int active_tiles = 0;
+  int tri_half = 1;    // half-MFMA k-tiles on the diagonal block of a triangular B (0 = off, tuning)
   long tri_row0 = 0;   // absolute row of C's first row (set when the host launches a row strip of a larger product)
   // optional row scaling of the physical A tile (fused elementwise work, no extra HBM pass):
   //   ascale_mode 1 (A not transposed): A[m][k] = ascale[m*as_ld + k / a_kblk] * Aphys[m][k % a_kblk]
@@ -356,20 +357,26 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 #endif
     }
   };
-  auto mma = [&](const double (&xa)[FM], const double (&xb)[FN][4]) {
+  // SK: 0 = all column blocks; 1 / 2 = the wave's first / last column block is skipped (k-tiles of a triangular
+  // operand's diagonal block where those 16-column blocks of B are structurally zero, see `skip_at` below)
+  auto mma = [&](auto sk_c, const double (&xa)[FM], const double (&xb)[FN][4]) {
+    constexpr int SK = decltype(sk_c)::value;
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
+    for (int j = 0; j < FN; ++j) {
+      if constexpr ((SK == 1 && FN == 2) || (SK == 2 && FN == 2)) { if (j == (SK == 1 ? 0 : FN - 1)) continue; }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           acc[i][j][e] = __builtin_amdgcn_mfma_f64_4x4x4f64(xa[i], xb[j][e], acc[i][j][e], 0, 0, 0);
+    }
   };
-  constexpr int N_MFMA = FM * FN * 4;                               // per half-step
+  constexpr int N_MFMA_FULL = FM * FN * 4;                          // per half-step
   constexpr int N_RA = TA ? 2 * FM : FM, N_RB = TB ? 4 * FN : 2 * FN;   // LDS read instructions of fragA / fragB
   constexpr int N_WRITE = Cfg::A_PASS + Cfg::B_PASS;
-  auto hint = [&](auto nw_c, auto nr_c) {   // nw LDS writes first, then nr LDS reads, spread over the unit's MFMAs
+  auto hint = [&](auto sk_c, auto nw_c, auto nr_c) {   // nw LDS writes first, then nr LDS reads, spread over the unit's MFMAs
     constexpr int nw = decltype(nw_c)::value, nr = decltype(nr_c)::value;
+    constexpr int N_MFMA = (decltype(sk_c)::value != 0 && FN == 2) ? N_MFMA_FULL / 2 : N_MFMA_FULL;
     constexpr int per = N_MFMA / (nw + nr) > 0 ? N_MFMA / (nw + nr) : 1;
 #pragma unroll
     for (int n = 0; n < nw; ++n) {
@@ -389,22 +396,22 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   // stores sit in the same basic block as the MFMAs.  That buffer was last read before the previous barrier
   // (every wave drains its LDS reads before it arrives there).  `fetch_next2` starts the global loads of a later
   // tile into the registers the store has freed.
-  auto ktile = [&](int cur, auto&& stage_next, auto&& fetch_next2) {
+  auto ktile = [&](auto sk, int cur, auto&& stage_next, auto&& fetch_next2) {
 #pragma unroll
     for (int s8 = 0; s8 < NS; ++s8) {
       // half-step (s8, 0): B fragments of (s8, 1) fly
       fragB(cur, s8, 1, fb[1]);
-      mma(fa[s8 & 1][0], fb[0]);
-      hint(integral_constant<int, 0>{}, integral_constant<int, N_RB>{});
+      mma(sk, fa[s8 & 1][0], fb[0]);
+      hint(sk, integral_constant<int, 0>{}, integral_constant<int, N_RB>{});
       __builtin_amdgcn_sched_barrier(0);
       if (s8 < NS - 1) {
         // half-step (s8, 1): fragments of (s8 + 1, 0) fly; the last such unit also carries the LDS stores
         if (s8 == NS - 2) stage_next();
         fragA(cur, s8 + 1, fa[(s8 + 1) & 1]);
         fragB(cur, s8 + 1, 0, fb[0]);
-        mma(fa[s8 & 1][1], fb[1]);
-        if (s8 == NS - 2) hint(integral_constant<int, N_WRITE>{}, integral_constant<int, N_RA + N_RB>{});
-        else hint(integral_constant<int, 0>{}, integral_constant<int, N_RA + N_RB>{});
+        mma(sk, fa[s8 & 1][1], fb[1]);
+        if (s8 == NS - 2) hint(sk, integral_constant<int, N_WRITE>{}, integral_constant<int, N_RA + N_RB>{});
+        else hint(sk, integral_constant<int, 0>{}, integral_constant<int, N_RA + N_RB>{});
         __builtin_amdgcn_sched_barrier(0);
       } else {
 #ifndef DGP_ABLATE_BARRIER
@@ -415,12 +422,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
         // last half-step: the first fragments of the next k-tile fly (harmless after the last k-tile: valid LDS)
         fragA(cur ^ 1, 0, fa[0]);
         fragB(cur ^ 1, 0, 0, fb[0]);
-        mma(fa[s8 & 1][1], fb[1]);
-        hint(integral_constant<int, 0>{}, integral_constant<int, N_RA + N_RB>{});
+        mma(sk, fa[s8 & 1][1], fb[1]);
+        hint(sk, integral_constant<int, 0>{}, integral_constant<int, N_RA + N_RB>{});
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
+  constexpr integral_constant<int, 0> SK0{};
   auto first_frags = [&]() { fragA(0, 0, fa[0]); fragB(0, 0, 0, fb[0]); };
 
   if constexpr (!FAST) {
@@ -436,7 +444,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     if (ktiles > 0) first_frags();
     for (long kt = 0; kt < ktiles; ++kt) {
       const int cur = (int)(kt & 1);
-      ktile(cur, [&]() { sstore(cur ^ 1); }, [&]() { if (kt + 2 < ktiles) gload(); });
+      ktile(SK0, cur, [&]() { sstore(cur ^ 1); }, [&]() { if (kt + 2 < ktiles) gload(); });
     }
   } else {
     // ---- interior fast path: running pointers, unconditional 16-byte loads, no predicates ----
@@ -536,15 +544,30 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     if (ktiles > 0) first_frags();
     // k-tile kt reads LDS buffer kt & 1, stores tile kt+1 (register set (kt+1) & 1) and then refills that set
     // with tile kt+3; two tiles per trip keep the set indices compile-time.
-    for (long kt = 0; kt < ktiles; kt += 2) {
+    // Triangular B with 64-column tiles: inside the diagonal 64 x 64 block of B, the k-tiles (16 rows of B each) meet
+    // 16-column blocks that are structurally zero.  Block cb of the tile belongs to wave column wc as j = cb / WC
+    // (cb = j * WC + wc), so in the LAST two k-tiles of an upper-triangular range (rows >= 32 of the diagonal block)
+    // both waves' j = 0 blocks (columns < 32) are zero, and in the FIRST two of a lower-triangular range both waves'
+    // j = 1 blocks are: those k-tiles issue half of the MFMAs (the other two diagonal k-tiles keep one wave busy
+    // with both of its blocks, so nothing is gained there).  10 % of the MFMA work of an M = 256 triangular product.
+    // Handled as separate phases before / after the main loop (single triangular block only), not as a branch
+    // inside it: a three-way dispatch per k-tile made hipcc spill ~400 VGPRs in every instantiation.
+    const int tri_sk = (FN != 2 || WC != 2 || !tri_ok || !g.tri_half || nkb != 1 || khi - klo < 4 * BK || (ktiles & 1)) ? 0
+                       : (g.tri == TRI_B_UPPER ? 1 : (g.tri == TRI_B_LOWER ? 2 : 0));
+    auto pair = [&](auto sk, long kt) {
 #ifndef DGP_ABLATE_GLOBAL
-      ktile(0, [&]() { fstore(1, 1); }, [&]() { if (kt + 3 < ktiles) fload(1); });
-      if (kt + 1 < ktiles) ktile(1, [&]() { fstore(0, 0); }, [&]() { if (kt + 4 < ktiles) fload(0); });
+      ktile(sk, 0, [&]() { fstore(1, 1); }, [&]() { if (kt + 3 < ktiles) fload(1); });
+      if (kt + 1 < ktiles) ktile(sk, 1, [&]() { fstore(0, 0); }, [&]() { if (kt + 4 < ktiles) fload(0); });
 #else
-      ktile(0, [&]() {}, [&]() {});
-      if (kt + 1 < ktiles) ktile(1, [&]() {}, [&]() {});
+      ktile(sk, 0, [&]() {}, [&]() {});
+      if (kt + 1 < ktiles) ktile(sk, 1, [&]() {}, [&]() {});
 #endif
-    }
+    };
+    long kt = 0;
+    if (tri_sk == 2) { pair(integral_constant<int, 2>{}, 0); kt = 2; }
+    const long kt_end = tri_sk == 1 ? ktiles - 2 : ktiles;
+    for (; kt < kt_end; kt += 2) pair(SK0, kt);
+    if (tri_sk == 1) pair(integral_constant<int, 1>{}, ktiles - 2);
   }
 
   // ---- epilogue: acc[i][j][e] of lane l is C[rowblk*16 + 4*((l&15)>>2) + (l>>4)][colblk*16 + 4*(l&3) + e]

@@ -38,6 +38,9 @@ static hipError_t launch(hipStream_t st, GemmArgs a) {
     e = getenv("DGP_GEMM_GRID_MIN"); gmin = e ? atol(e) : 1016; if (gmin > gmax) gmin = gmax;
     e = getenv("DGP_GEMM_TILES_PER_WG"); per = e ? atol(e) : 4; if (per < 1) per = 1;
   }
+  static int tri_half = -1;
+  if (tri_half < 0) { const char* e = getenv("DGP_TRI_HALF"); tri_half = e ? atoi(e) : 1; }
+  a.tri_half = tri_half;
   if (!grouped && gx > gmin) {
     // ~`per` tiles per workgroup amortise the launch cost of a workgroup, few enough workgroups leave the
     // balancing of unequal (triangular) tiles to the hardware dispatcher: 8 * odd, between gmin and gmax
