@@ -64,6 +64,9 @@ struct GemmArgs {
   // tiles are launched: early-exit workgroups were measured to cost as much as running ones); 0 = full grid
   int active_tiles = 0;
   int tri_half = 1;    // half-MFMA k-tiles on the diagonal block of a triangular B (0 = off, tuning)
+  int tri_part = 0;    // TRI_OUT_LOWER with a compact grid: 0 = every active tile; 1 = only tiles that need all their
+                       // rows; 2 = only tiles whose first BM/2 rows lie strictly above the diagonal (kernel ROWSEL = 1
+                       // runs those with half of the MFMAs).  The host launches parts 1 and 2 back to back.
   long tri_row0 = 0;   // absolute row of C's first row (set when the host launches a row strip of a larger product)
   // optional row scaling of the physical A tile (fused elementwise work, no extra HBM pass):
   //   ascale_mode 1 (A not transposed): A[m][k] = ascale[m*as_ld + k / a_kblk] * Aphys[m][k % a_kblk]
@@ -157,7 +160,8 @@ __device__ __forceinline__ void tile_store(const double (&reg)[PASS][V], double*
 // issues unconditional 16-byte loads and carries no predicates — the generic loader's ~330 non-MFMA
 // instructions per k-tile made the loop issue-bound (two waves share a SIMD's issue port with the MFMAs).
 // SCALED (FAST only): A-operand row scaling of GemmArgs::ascale_mode.
-template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int VB, bool FAST = false, bool SCALED = false>
+template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int VB, bool FAST = false, bool SCALED = false,
+          int ROWSEL = 0 /* 1: only the half-needed tiles of a lower-triangular output, see tri_part */>
 #ifndef DGP_WAVES_PER_EU   // two workgroups per CU (LDS allows no more): cap the register budget at 256 per lane
 #define DGP_WAVES_PER_EU 2
 #endif
@@ -212,7 +216,11 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     tm_u = tn_u = 0;
     for (unsigned t = 0; t < tiles_n * tiles_m; ++t) {
       const unsigned a = t / tiles_n, b = t - a * tiles_n;
-      const bool act = ((unsigned)g.tri_row0 + a * BM + BM - 1) >= ((b * BN) % (unsigned)g.triblk);
+      bool act = ((unsigned)g.tri_row0 + a * BM + BM - 1) >= ((b * BN) % (unsigned)g.triblk);
+      if (g.tri_part != 0) {
+        const bool half = ((unsigned)g.tri_row0 + a * BM + BM / 2) <= ((b * BN) % (unsigned)g.triblk);
+        act = act && (half == (g.tri_part == 2));
+      }
       if (act) { if (cnt == bid) { tm_u = a; tn_u = b; } ++cnt; }
     }
   } else {
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     for (int j = 0; j < FN; ++j) {
       if constexpr ((SK == 1 && FN == 2) || (SK == 2 && FN == 2)) { if (j == (SK == 1 ? 0 : FN - 1)) continue; }
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+      for (int i = (SK == 3) ? FM / 2 : 0; i < FM; ++i)      // SK 3: the tile's first BM/2 rows are not needed
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           acc[i][j][e] = __builtin_amdgcn_mfma_f64_4x4x4f64(xa[i], xb[j][e], acc[i][j][e], 0, 0, 0);
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   constexpr int N_WRITE = Cfg::A_PASS + Cfg::B_PASS;
   auto hint = [&](auto sk_c, auto nw_c, auto nr_c) {   // nw LDS writes first, then nr LDS reads, spread over the unit's MFMAs
     constexpr int nw = decltype(nw_c)::value, nr = decltype(nr_c)::value;
-    constexpr int N_MFMA = (decltype(sk_c)::value != 0 && FN == 2) ? N_MFMA_FULL / 2 : N_MFMA_FULL;
+    constexpr int N_MFMA = (decltype(sk_c)::value == 3 || (decltype(sk_c)::value != 0 && FN == 2)) ? N_MFMA_FULL / 2 : N_MFMA_FULL;
     constexpr int per = N_MFMA / (nw + nr) > 0 ? N_MFMA / (nw + nr) : 1;
 #pragma unroll
     for (int n = 0; n < nw; ++n) {
@@ -563,11 +571,20 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       if (kt + 1 < ktiles) ktile(sk, 1, [&]() {}, [&]() {});
 #endif
     };
-    long kt = 0;
-    if (tri_sk == 2) { pair(integral_constant<int, 2>{}, 0); kt = 2; }
-    const long kt_end = tri_sk == 1 ? ktiles - 2 : ktiles;
-    for (; kt < kt_end; kt += 2) pair(SK0, kt);
-    if (tri_sk == 1) pair(integral_constant<int, 1>{}, ktiles - 2);
+    if constexpr (ROWSEL == 1) {
+      // Lower-triangular OUTPUT, 128 x 64 tiles: the tiles whose first 64 rows lie strictly above the diagonal need
+      // only the row blocks i >= FM/2 of both wave rows (row block = i * WR + wr): their whole K loop runs with half of
+      // the MFMAs.  Two of the six active tiles of a 256 x 256 block are of this kind (Gram and Q products); they
+      // are launched as their own grid (tri_part 2) with this instantiation, because a second copy of the loop
+      // inside the general kernel made hipcc spill.
+      for (long kt = 0; kt < ktiles; kt += 2) pair(integral_constant<int, 3>{}, kt);
+    } else {
+      long kt = 0;
+      if (tri_sk == 2) { pair(integral_constant<int, 2>{}, 0); kt = 2; }
+      const long kt_end = tri_sk == 1 ? ktiles - 2 : ktiles;
+      for (; kt < kt_end; kt += 2) pair(SK0, kt);
+      if (tri_sk == 1) pair(integral_constant<int, 1>{}, ktiles - 2);
+    }
   }
 
   // ---- epilogue: acc[i][j][e] of lane l is C[rowblk*16 + 4*((l&15)>>2) + (l>>4)][colblk*16 + 4*(l&3) + e]
@@ -628,7 +645,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       const long o00 = (m0 + (long)wr * 16 + 4 * (li >> 2) + lk) * g.ldc + n0 + (long)wc * 16 + 4 * (li & 3);
       const long istep = (long)WR * 16 * g.ldc;
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+      for (int i = (ROWSEL == 1 ? FM / 2 : 0); i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           const long o = o00 + i * istep + (long)j * WC * 16;
@@ -644,7 +661,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
+  for (int i = (ROWSEL == 1 ? FM / 2 : 0); i < FM; ++i) {    // ROWSEL 1: rows above the diagonal are neither computed nor stored
     double esc = 0.0;
     if (g.eadd != nullptr) {
       const long row = m0 + (long)(i * WR + wr) * 16 + 4 * (li >> 2) + lk;

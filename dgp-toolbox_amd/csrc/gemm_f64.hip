@@ -1,6 +1,7 @@
 // Host-side dispatch of the fp64 MFMA GEMM engine (see gemm_f64.h).
 #include "gemm_f64.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace dgp {
 
@@ -46,6 +47,26 @@ static hipError_t launch(hipStream_t st, GemmArgs a) {
     // balancing of unequal (triangular) tiles to the hardware dispatcher: 8 * odd, between gmin and gmax
     long want = ((tiles / per / 8) | 1) * 8;
     gx = want < gmin ? gmin : (want > gmax ? gmax : want);
+  }
+  if constexpr (FAST && BM == 128 && BN == 64 && WR == 2) {
+    // lower-triangular output: the tiles that need only their last 64 rows go to the half-MFMA instantiation
+    if (a.active_tiles > 0 && a.tri_half) {
+      long n_half = 0;
+      for (long m0 = 0; m0 < a.M; m0 += BM)
+        for (long n0 = 0; n0 < a.N; n0 += BN)
+          if (a.tri_row0 + m0 + BM - 1 >= n0 % a.triblk && a.tri_row0 + m0 + BM / 2 <= n0 % a.triblk) ++n_half;
+      if (n_half > 0 && n_half < tiles) {
+        GemmArgs f = a, h = a;
+        f.tri_part = 1; f.active_tiles = (int)(tiles - n_half);
+        h.tri_part = 2; h.active_tiles = (int)n_half;
+        long gf = grouped ? tiles - n_half : std::min<long>(gx, tiles - n_half), gh = grouped ? n_half : std::min<long>(gx, n_half);
+        hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, VA, VB, FAST, SCALED, 0>),
+                           dim3((unsigned)gf, (unsigned)(a.batch * a.splits), 1), dim3(256), 0, st, f);
+        hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, VA, VB, FAST, SCALED, 1>),
+                           dim3((unsigned)gh, (unsigned)(a.batch * a.splits), 1), dim3(256), 0, st, h);
+        return hipGetLastError();
+      }
+    }
   }
   dim3 grid((unsigned)gx, (unsigned)(a.batch * a.splits), 1);
   hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, BK, WR, WC, VA, VB, FAST, SCALED>), grid, dim3(256), 0, st, a);
