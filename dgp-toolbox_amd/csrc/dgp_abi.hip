@@ -87,9 +87,9 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
   int Mpmax = 0, Dmax = 0;
   for (int l = 0; l < n_layers; ++l) {
     const dgp_layer_desc& d = layers[l];
-    if (d.D_in <= 0 || d.D_in > 64 || d.D_out <= 0 || d.M <= 0 || d.M > 1024 || d.D_out > 65535 || d.kernel_kind < DGP_KERNEL_RBF || d.kernel_kind > DGP_KERNEL_MF ||
+    if (d.D_in <= 0 || d.D_in > 64 || d.D_out <= 0 || d.M <= 0 || d.M > 4096 || d.D_out > 65535 || d.kernel_kind < DGP_KERNEL_RBF || d.kernel_kind > DGP_KERNEL_MF ||
         d.mean_kind < 0 || d.mean_kind > 2 || d.kernel_white < 0 || d.kernel_white > 1)
-      return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: unsupported layer description (M <= 1024, D_in <= 64)");
+      return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: unsupported layer description (M <= 4096, D_in <= 64)");
     if (d.kernel_kind == DGP_KERNEL_MF && (d.D_in < 2 || d.D_in > 33 || d.mean_kind != DGP_MEAN_ZERO))
       return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: the multi-fidelity kernel needs 2 <= D_in <= 33 and a zero mean function");
     if (l > 0 && d.D_in != layers[l - 1].D_out) return fail(ctx, DGP_ERR_INVALID, "dgp_model_set: layer dims do not chain");

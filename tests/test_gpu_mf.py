@@ -188,3 +188,46 @@ def test_mf_dgp_em_training_phases_and_prediction(capsys):
         mean, var = mf.predict(Xt)
         assert mean.shape == (20, 1) and var.shape == (20, 1) and np.all(var > 0) and np.all(np.isfinite(mean))
         assert np.sqrt(np.mean((mean - hf(Xt)) ** 2)) < np.std(Y[1])
+
+
+def test_more_than_1024_inducing_points():
+    """M = N per fidelity in the multi-fidelity model (q_mu.assign(Y), MF_DGP_EM.py:435-447), so the blocked
+    factorisation has to go past the M = 1024 of the headline configurations: one RBF + White layer with M = 1100
+    (padded to 1152), forward and gradients against the torch restatement."""
+    import torch
+    import mf_dgp_em_oracle as mo
+    from dgp_dace import _native
+    rng = np.random.default_rng(2)
+    M, P, Din, D = 1100, 150, 3, 1
+    Z = rng.uniform(0, 1, (M, Din))
+    X = rng.uniform(0, 1, (P, Din))
+    var, ls, wv = 1.2, np.array([0.25, 0.3, 0.35]), 0.01
+    q_mu = rng.standard_normal((M, D))
+    q_sqrt = (np.tril(rng.standard_normal((D, M, M)) * 0.01) + 0.3 * np.eye(M)[None])
+    layer = {"kern": {"type": "rbf", "variance": mo._t(var), "lengthscales": mo._t(ls), "white_variance": mo._t(wv)},
+             "Z": mo._t(Z), "q_mu": mo._t(q_mu), "q_sqrt": mo._t(q_sqrt)}
+    z = rng.standard_normal((1, P, D))
+    mb, vb = rng.standard_normal((1, P, D)), rng.standard_normal((1, P, D))
+    Xt = torch.tensor(X, dtype=mo.DT, requires_grad=True)
+    F, mean, v = mo.sample_layer(layer, layer["Z"], Xt, torch.as_tensor(z[0]))
+    kl = mo.layer_KL(layer, layer["Z"])
+    ((torch.as_tensor(mb[0]) * mean + torch.as_tensor(vb[0]) * v).sum() - kl).backward()
+    ctx = _native.Context(0)
+    flat = np.concatenate([Z.ravel(), [var], ls, [wv], q_mu.ravel(), q_sqrt.ravel(), [1.0]])
+    ctx.model_set([(Din, D, M, 0, 0, 0, 1)], flat, None)
+    _, Fm, Fv = ctx.propagate(X, 1, 0, [z])
+    np.testing.assert_allclose(Fm[0][0], mean.detach().numpy(), rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(Fv[0][0], v.detach().numpy(), rtol=1e-6, atol=1e-8)
+    xbar = ctx.propagate_vjp(X, 1, 0, [z], mean_bar=mb, var_bar=vb, accumulate="reset")
+    np.testing.assert_allclose(xbar, Xt.grad.numpy(), rtol=1e-5, atol=1e-6 * np.abs(Xt.grad.numpy()).max())
+    assert abs(ctx.grad_finish(want_elbo=True) + float(kl.detach())) <= 1e-8 * abs(float(kl.detach()))
+    g = ctx.grad_get()
+    gz = layer["Z"].grad.numpy()
+    np.testing.assert_allclose(g[:M * Din].reshape(M, Din), gz, rtol=1e-5, atol=1e-6 * np.abs(gz).max())
+    off = M * Din
+    for nm, n in (("variance", 1), ("lengthscales", Din), ("white_variance", 1)):
+        ref = np.atleast_1d(layer["kern"][nm].grad.numpy())
+        np.testing.assert_allclose(g[off:off + n], ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max(), err_msg=nm)
+        off += n
+    gq = layer["q_mu"].grad.numpy()
+    np.testing.assert_allclose(g[off:off + M * D].reshape(M, D), gq, rtol=1e-5, atol=1e-6 * np.abs(gq).max())

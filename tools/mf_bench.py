@@ -1,7 +1,7 @@
 """Timing of the MF-DGP-EM bound + gradient on one GPU (BASELINE.json config 5 at the sizes the engine takes).
 
 The reference assigns q_mu = Y per fidelity (MF_DGP_EM.py:435-447), i.e. M = N for every layer; the device
-factorisation is sized for M <= 1024, so the low-fidelity set is capped at 1024 points here (config 5 as written,
+library accepts M <= 4096, so the low-fidelity set is capped at 4096 points here (config 5 as written,
 N_lf = 50 000, would need M = 50 000)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ import numpy as np
 from dgp_dace.models.MF_DGP_EM import MultiFidelityDeepGP_EM
 
 rng = np.random.default_rng(0)
-for (n_lf, n_hf, S) in ((200, 50, 100), (1000, 100, 100), (1024, 256, 100)):
+for (n_lf, n_hf, S) in ((200, 50, 100), (1000, 100, 100), (1024, 256, 100), (2048, 512, 100), (4096, 512, 100)):
     X0, X1 = rng.uniform(0, 1, (n_lf, 4)), rng.uniform(0, 1, (n_hf, 2))
     lf = lambda x: np.sin(4 * x[:, :1]) + x[:, 1:2] * x[:, 2:3] - 0.5 * x[:, 3:4]
     X_red = [np.concatenate([X1, 0.5 * np.ones((n_hf, 2))], 1)]
