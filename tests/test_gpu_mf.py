@@ -231,3 +231,26 @@ def test_more_than_1024_inducing_points():
         off += n
     gq = layer["q_mu"].grad.numpy()
     np.testing.assert_allclose(g[off:off + M * D].reshape(M, D), gq, rtol=1e-5, atol=1e-6 * np.abs(gq).max())
+
+
+def test_mf_natural_gradient_step_matches_the_closed_form():
+    """Part 3 of optimize_nat_adam (MF_DGP_EM.py:562-573): NaturalGradient on every layer's (q_mu, q_sqrt), here the
+    device step after a bound evaluation against the XiNat closed form fed with the restatement's gradients."""
+    import dgp_oracle as O
+    import mf_dgp_em_oracle as mo
+    rng = np.random.default_rng(21)
+    X, Y, X_red = _mf_problem(rng, 2)
+    S = 3
+    mf, P, names = _pair_models(rng, X, Y, X_red, S)
+    normals = mo.draw_normals(rng, X, P, S)
+    _, _, g_ref = mo.elbo_and_grads(P, X, Y, X_red, normals, S)
+    mf.model.ELBO_and_grad((X, Y, X_red), normals=normals)
+    gamma = 1e-5          # the random state has steep gradients: a step that keeps Sigma^-1 + 2 gamma G positive definite
+    for lay in list(mf.model.layers) + list(mf.model.layers_red):
+        q_mu, q_sqrt = lay.q_mu._value.copy(), lay.q_sqrt._value.copy()
+        want_mu, want_sq = O.natgrad_step(q_mu, q_sqrt, -g_ref[names[id(lay.q_mu)]], -g_ref[names[id(lay.q_sqrt)]], gamma)
+        lay.natgrad_step(gamma)
+        for got, want, old in ((lay.q_mu._value, want_mu, q_mu), (lay.q_sqrt._value, want_sq, q_sqrt)):
+            step = np.abs(want - old).max()
+            assert step > 1e-9                                   # the step is visible ...
+            np.testing.assert_allclose(got - old, want - old, rtol=1e-4, atol=1e-6 * step)   # ... and equal
