@@ -426,6 +426,14 @@ class DGP_Base:
         Fmean, Fvar = self.predict_f(Xnew, full_cov=full_cov, S=num_samples)
         return Fmean, as_tensor(Fvar + float(self.likelihood.likelihood.variance._value))
 
+    def predict_density(self, Xnew, Ynew, num_samples):
+        """log of the mixture predictive density, averaged over the samples (MF_DGP_EM.py:318-322)."""
+        Fmean, Fvar = self.predict_f(Xnew, full_cov=False, S=num_samples)
+        v = np.asarray(Fvar) + float(self.likelihood.likelihood.variance._value)
+        l = -0.5 * np.log(2 * np.pi * v) - 0.5 * (np.asarray(Ynew)[None] - np.asarray(Fmean)) ** 2 / v
+        m = l.max(0)
+        return as_tensor(m + np.log(np.exp(l - m).sum(0)) - np.log(num_samples))
+
     # ---- the bound and its gradient ----
     def _noise(self, f):
         """(value, Parameter) of the Gaussian noise of fidelity f: the likelihood's variance at the top, the White

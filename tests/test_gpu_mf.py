@@ -188,6 +188,8 @@ def test_mf_dgp_em_training_phases_and_prediction(capsys):
         mean, var = mf.predict(Xt)
         assert mean.shape == (20, 1) and var.shape == (20, 1) and np.all(var > 0) and np.all(np.isfinite(mean))
         assert np.sqrt(np.mean((mean - hf(Xt)) ** 2)) < np.std(Y[1])
+        dens = mf.model.predict_density(Xt, hf(Xt), 20)
+        assert dens.shape == (20, 1) and np.all(np.isfinite(dens))
 
 
 def test_more_than_1024_inducing_points():
