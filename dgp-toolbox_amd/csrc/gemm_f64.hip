@@ -55,7 +55,11 @@ static hipError_t launch(hipStream_t st, GemmArgs a) {
       for (long m0 = 0; m0 < a.M; m0 += BM)
         for (long n0 = 0; n0 < a.N; n0 += BN)
           if (a.tri_row0 + m0 + BM - 1 >= n0 % a.triblk && a.tri_row0 + m0 + BM / 2 <= n0 % a.triblk) ++n_half;
-      if (n_half > 0 && n_half < tiles) {
+      // (a half part of fewer workgroups than the chip has slots would run as an under-filled launch of its own:
+      //  small shards and single-output layers keep the one-launch form)
+      static long min_half = -1;
+      if (min_half < 0) { const char* e = getenv("DGP_HALF_MIN_WG"); min_half = e ? atol(e) : 384; }
+      if (n_half > 0 && n_half < tiles && n_half * a.batch * a.splits >= min_half) {
         GemmArgs f = a, h = a;
         f.tri_part = 1; f.active_tiles = (int)(tiles - n_half);
         h.tri_part = 2; h.active_tiles = (int)n_half;
