@@ -14,9 +14,21 @@ import os
 import sys
 
 
+SHARD_ALIGN = 16      # k-tile of the reductions over points: an aligned shard needs no tail launch (gemm_f64.hip)
+
+
 def shard_bounds(N, rank, world):
-    """Contiguous, balanced split of N points: rank r owns [lo, hi)."""
-    return (rank * N) // world, ((rank + 1) * N) // world
+    """Contiguous, balanced split of N points: rank r owns [lo, hi).  Interior boundaries sit on multiples of 16 when
+    every shard stays non-empty (the sizes then differ by at most 16 + 1 points), so that the products that reduce over
+    a rank's points (K = number of points, 16 per k-tile) have no ragged tail."""
+    def cut(r):
+        if r <= 0:
+            return 0
+        if r >= world:
+            return N
+        b = (r * N) // world
+        return b if N < 2 * SHARD_ALIGN * world else ((b + SHARD_ALIGN // 2) // SHARD_ALIGN) * SHARD_ALIGN
+    return cut(rank), cut(rank + 1)
 
 
 class Dist:
