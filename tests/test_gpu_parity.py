@@ -191,6 +191,33 @@ def test_medium_size_against_oracle():
             assert np.abs(Gp[(i, k)] - ref).max() < 1e-6 * max(1.0, np.abs(ref).max()), (i, k)
 
 
+def test_config4_shape_against_oracle():
+    """BASELINE config 4's architecture (`[16,16,16]` -> 4 SVGP layers, D=16, M=512) on a few hundred points:
+    ELBO, every layer's gradients and one natural-gradient step against the restatement."""
+    import dgp_oracle_torch as T
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    rng = np.random.default_rng(4)
+    N, D, M, S = 700, 16, 512, 2
+    X = rng.standard_normal((N, D)); Y = np.sin(X[:, :1]) + 0.1 * rng.standard_normal((N, 1))
+    Z = X[rng.permutation(N)[:M]].copy()
+    m = DGP(X, Y, Z, [RBF(1.0, 2.0 * np.ones(D)) for _ in range(4)], [16, 16, 16], Gaussian(), num_samples=S)
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(1.0, 2.0 * np.ones(D)) for _ in range(4)], [16, 16, 16], num_samples=S)
+    for l, lo in zip(m.layers[:-1], mo.layers[:-1]):
+        l.q_sqrt.assign(l.q_sqrt * 1e-1); lo.q_sqrt = lo.q_sqrt * 1e-1
+    ctx = m._sync_model()
+    m._sync_data(m.data)
+    ctx.grad_partial(S, 5, None)
+    elbo = ctx.grad_finish(want_elbo=True)
+    eo, G = T.elbo_and_grads(mo, O.draw_zs(mo, 5, S, N))
+    assert abs(elbo - eo) < 1e-8 * abs(eo)
+    Gp = split_flat(m, ctx.grad_get())
+    for i in range(4):
+        for k in ("Z", "lengthscales", "variance", "q_mu", "q_sqrt"):
+            ref = G["layers"][i][k]
+            assert np.abs(Gp[(i, k)] - ref).max() < 1e-6 * max(1.0, np.abs(ref).max()), (i, k)
+
+
 DIST_WORKER = r'''
 import os, sys
 sys.path[:0] = [os.path.join(ROOT, "dgp-toolbox_amd"), os.path.join(ROOT, "tests")]
