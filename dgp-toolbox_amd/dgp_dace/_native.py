@@ -203,6 +203,8 @@ class Context:
         outs = []
         for w in want:
             outs.append([np.empty((S, Nn, d)) if w else None for d in self.douts])
+        if Nn == 0:          # no points: empty [S, 0, D_l] results, as the reference's tensors would be
+            return outs
         ptrs = [_ptr_array(o) for o in outs]
         self._chk(self._lib.dgp_propagate(self._h, _ptr(Xnew), Nn, int(S), int(seed) & (2 ** 64 - 1), zp, ptrs[0],
                                           ptrs[1], ptrs[2], 1 if add_lik_var else 0))

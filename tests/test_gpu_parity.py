@@ -191,6 +191,19 @@ def test_medium_size_against_oracle():
             assert np.abs(Gp[(i, k)] - ref).max() < 1e-6 * max(1.0, np.abs(ref).max()), (i, k)
 
 
+def test_empty_prediction_set():
+    """No points in, empty [S, 0, D] arrays out (what the reference's TensorFlow ops return for N = 0)."""
+    from helpers import load, product_from_golden
+    m = product_from_golden(load("case_B_nonwhite"), seed=1)
+    D = m.layers[0].feature.Z.shape[1]
+    Fs, Fm, Fv = m.propagate(np.zeros((0, D)), S=3)
+    assert [a.shape for a in Fs] == [(3, 0, l.num_outputs) for l in m.layers] and len(Fm) == len(Fv) == len(m.layers)
+    mean, var = m.predict_y(np.zeros((0, D)), 4)
+    assert mean.shape == var.shape == (4, 0, m.layers[-1].num_outputs)
+    mu, v = m.predict(np.zeros((0, D)), 4)
+    assert mu.shape == v.shape == (0, m.layers[-1].num_outputs)
+
+
 def test_config4_shape_against_oracle():
     """BASELINE config 4's architecture (`[16,16,16]` -> 4 SVGP layers, D=16, M=512) on a few hundred points:
     ELBO, every layer's gradients and one natural-gradient step against the restatement."""
