@@ -256,3 +256,48 @@ def test_mf_natural_gradient_step_matches_the_closed_form():
             step = np.abs(want - old).max()
             assert step > 1e-9                                   # the step is visible ...
             np.testing.assert_allclose(got - old, want - old, rtol=1e-4, atol=1e-6 * step)   # ... and equal
+
+
+def test_mf_kernel_and_white_variance_inside_a_two_layer_stack():
+    """The same kernels as layers of an ordinary stack (dgp_elbo / dgp_grad_partial path: Gaussian likelihood on the
+    device, the x-gradient of the MF layer folded into the layer below): RBF + White (2 -> 2), then the MF kernel on
+    [x, f] = the two outputs of the first layer (2 -> 1)."""
+    import math
+    import torch
+    import mf_dgp_em_oracle as mo
+    from dgp_dace import _native
+    rng = np.random.default_rng(9)
+    N, S, M = 40, 3, 13
+    X = rng.uniform(-1, 1, (N, 2)); Y = rng.standard_normal((N, 1))
+    l1, _, f1, d1, _ = _layer_case("rbf", True, 2, rng, M=M, P=1, Dx=2)
+    l2, _, f2, d2, _ = _layer_case("mf", False, 1, rng, M=M, P=1, Dx=1)
+    lik = 0.4
+    flat = np.concatenate([f1[:-1], f2[:-1], [lik]])
+    zs = [rng.standard_normal((S, N, 2)), rng.standard_normal((S, N, 1))]
+    # restatement
+    Xt = torch.as_tensor(np.tile(X[None], (S, 1, 1)).reshape(S * N, 2))
+    F1, _, _ = mo.sample_layer(l1, l1["Z"], Xt, torch.as_tensor(zs[0].reshape(S * N, 2)))
+    _, mean, var = mo.sample_layer(l2, l2["Z"], F1, torch.as_tensor(zs[1].reshape(S * N, 1)))
+    Yt = torch.as_tensor(np.tile(Y[None], (S, 1, 1)).reshape(S * N, 1))
+    data = (-0.5 * math.log(2 * math.pi) - 0.5 * math.log(lik) - 0.5 * ((Yt - mean) ** 2 + var) / lik).sum() / S
+    kl = mo.layer_KL(l1, l1["Z"]) + mo.layer_KL(l2, l2["Z"])
+    (data - kl).backward()
+    # device
+    ctx = _native.Context(0)
+    ctx.model_set([d1, d2], flat, None)
+    ctx.data_set(X, Y)
+    L, KL = ctx.elbo(S, 0, zs)
+    assert abs(L - float(data.detach())) <= 1e-9 * abs(float(data.detach())) and abs(KL - float(kl.detach())) <= 1e-9 * abs(float(kl.detach()))
+    ctx.grad_partial(S, 0, zs)
+    ctx.grad_finish()
+    g = ctx.grad_get()
+    off = 0
+    for lay, names in ((l1, ["variance", "lengthscales", "white_variance"]),
+                       (l2, ["corr_variance", "corr_lengthscales", "prev_variance", "prev_lengthscales", "lin_variance",
+                             "in_variance", "in_lengthscales"])):
+        refs = [lay["Z"].grad.numpy()] + [np.atleast_1d(lay["kern"][n].grad.numpy()) for n in names] + \
+               [lay["q_mu"].grad.numpy(), np.tril(lay["q_sqrt"].grad.numpy())]
+        for ref in refs:
+            got = g[off:off + ref.size].reshape(ref.shape)
+            np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(ref).max()))
+            off += ref.size
