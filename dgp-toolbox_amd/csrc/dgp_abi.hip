@@ -192,6 +192,7 @@ int dgp_data_set(dgp_ctx* ctx, const double* X, const double* Y, int64_t N, int3
   HIPCHK(hipMemcpy(ctx->X, X, (size_t)N * D * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ctx->Y, Y, (size_t)N * Dy * 8, hipMemcpyHostToDevice));
   ctx->N = N; ctx->D = D; ctx->Dy = Dy; ctx->n_goff = n_global_offset;
+  ctx->batch_lo = ctx->batch_n = 0; ctx->data_scale = 1.0;          // a new data set starts with the full-batch bound
   return DGP_OK;
 }
 
@@ -212,6 +213,15 @@ static int check_ready(dgp_ctx* ctx, bool need_data) {
   return DGP_OK;
 }
 
+int dgp_batch_set(dgp_ctx* ctx, int64_t start, int64_t count, double scale) {
+  if (!ctx || start < 0 || count < 0 || !(scale > 0.0)) return fail(ctx, DGP_ERR_INVALID, "dgp_batch_set: bad arguments");
+  if (ctx->X && start + count > ctx->N) return fail(ctx, DGP_ERR_INVALID, "dgp_batch_set: window exceeds the resident points");
+  ctx->batch_lo = count ? start : 0;
+  ctx->batch_n = count;
+  ctx->data_scale = scale;
+  return DGP_OK;
+}
+
 int dgp_elbo(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs, double* data_term, double* kl) {
   RET(check_ready(ctx, true));
   if (S <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_elbo: S must be positive");
@@ -219,15 +229,16 @@ int dgp_elbo(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs, do
   if (zs) RET(upload_zs(ctx, zs, S, ctx->N));
   RET(prep(ctx));
   long Nc = 0;
-  RET(ensure_ws(ctx, ctx->N, S, false, &Nc));
+  const long lo = ctx->batch_n ? ctx->batch_lo : 0, hi = ctx->batch_n ? ctx->batch_lo + ctx->batch_n : ctx->N;
+  RET(ensure_ws(ctx, hi - lo, S, false, &Nc));
   Layer& last = ctx->L.back();
   const bool dedup_last = ctx->L.size() == 1;
-  for (long n0 = 0; n0 < ctx->N; n0 += Nc) {
-    const long nc = std::min(Nc, ctx->N - n0);
+  for (long n0 = lo; n0 < hi; n0 += Nc) {
+    const long nc = std::min(Nc, hi - n0);
     RET(forward_chunk(ctx, ctx->X, ctx->N, n0, nc, S, seed, zs != nullptr, ctx->n_goff));
     ProfScope ps(ctx, 1, 0, 0);
     HIPCHK(gauss_lik(ctx->st, last.mean, last.var, ctx->Y, n0, nc, S, dedup_last ? 1 : 0, ctx->Dy,
-                     P(ctx, ctx->n_params - 1), ctx->scal + 2, nullptr, nullptr, nullptr, nullptr));
+                     P(ctx, ctx->n_params - 1), ctx->scal + 2, nullptr, nullptr, nullptr, nullptr, ctx->data_scale));
   }
   double h[4];
   HIPCHK(hipMemcpyAsync(h, ctx->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->st));
@@ -435,17 +446,18 @@ int dgp_grad_partial(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const
   RET(prep(ctx, true));
   HIPCHK(hipMemsetAsync(ctx->acc, 0, ctx->n_acc * 8, ctx->st));
   long Nc = 0;
-  RET(ensure_ws(ctx, ctx->N, S, true, &Nc));
+  const long lo = ctx->batch_n ? ctx->batch_lo : 0, hi = ctx->batch_n ? ctx->batch_lo + ctx->batch_n : ctx->N;
+  RET(ensure_ws(ctx, hi - lo, S, true, &Nc));
   Layer& last = ctx->L.back();
   const bool dedup_last = ctx->L.size() == 1;
-  for (long n0 = 0; n0 < ctx->N; n0 += Nc) {
-    const long nc = std::min(Nc, ctx->N - n0);
+  for (long n0 = lo; n0 < hi; n0 += Nc) {
+    const long nc = std::min(Nc, hi - n0);
     RET(forward_chunk(ctx, ctx->X, ctx->N, n0, nc, S, seed, zs != nullptr, ctx->n_goff));
     {
       ProfScope ps(ctx, 1, 0, 0);
       HIPCHK(gauss_lik(ctx->st, last.mean, last.var, ctx->Y, n0, nc, S, dedup_last ? 1 : 0, ctx->Dy,
                        P(ctx, ctx->n_params - 1), ctx->acc + 0, ctx->acc + 1, last.mbar, last.vbar,
-                       ctx->acc + last.acc_dvar));
+                       ctx->acc + last.acc_dvar, ctx->data_scale));
     }
     RET(backward_chunk(ctx, n0, nc, S, seed, zs != nullptr, BwdOpts{ctx->X, ctx->N, ctx->n_goff, true, false}));
   }

@@ -81,6 +81,8 @@ struct dgp_ctx {
   long N = 0;
   int D = 0, Dy = 0;
   long n_goff = 0;
+  long batch_lo = 0, batch_n = 0;   // window of the resident points the bound is evaluated on (batch_n == 0: all of them)
+  double data_scale = 1.0;          // factor on the data term (N / batch size for a minibatch estimate)
   double *acc = nullptr, *acc_own = nullptr;
   long n_acc = 0;
   double* scal = nullptr;   // device scalars: [0] sum KL, [1] ELBO of last grad_finish, [2] scratch data term

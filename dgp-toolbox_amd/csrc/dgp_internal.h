@@ -112,7 +112,7 @@ hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, 
 // Gaussian variational expectations (gpflow Gaussian, via utils.py:89-93) + seeds of the backward pass
 hipError_t gauss_lik(hipStream_t st, const double* mean, const double* var, const double* Y, long y_row0, long Nc,
                      int S, int dedup, int Dy, const double* lik_var, double* acc_elbo, double* acc_dlik,
-                     double* mbar, double* vbar, double* acc_dkvar);
+                     double* mbar, double* vbar, double* acc_dkvar, double scale = 1.0);
 // fold dF into (mbar, vbar) of the producing layer; sums over s when dedup
 hipError_t fold_sample_grad(hipStream_t st, const double* Fbar, const double* var, long Nc, int S, int dedup, int D,
                             ZSource zsrc, long n_chunk0, double* mbar, double* vbar, double* acc_dkvar);

@@ -198,12 +198,12 @@ __global__ __launch_bounds__(256) void gauss_lik_kernel(const double* __restrict
                                                         int dedup, int Dy, const double* __restrict__ lik_var,
                                                         double* __restrict__ acc_elbo, double* __restrict__ acc_dlik,
                                                         double* __restrict__ mbar, double* __restrict__ vbar,
-                                                        double* __restrict__ acc_dkvar) {
+                                                        double* __restrict__ acc_dkvar, double scale) {
   __shared__ double sh[4];
   const long P = dedup ? Nc : (long)S * Nc;
   const long total = P * Dy;
   const double s2 = lik_var[0];
-  const double w = dedup ? 1.0 : 1.0 / (double)S;
+  const double w = scale * (dedup ? 1.0 : 1.0 / (double)S);     // scale: N / batch size of a minibatch (dgp.py:95-99)
   double e = 0.0, dl = 0.0, dk = 0.0;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const long p = idx / Dy;
@@ -230,13 +230,13 @@ __global__ __launch_bounds__(256) void gauss_lik_kernel(const double* __restrict
 
 hipError_t gauss_lik(hipStream_t st, const double* mean, const double* var, const double* Y, long y_row0, long Nc, int S,
                      int dedup, int Dy, const double* lik_var, double* acc_elbo, double* acc_dlik, double* mbar,
-                     double* vbar, double* acc_dkvar) {
+                     double* vbar, double* acc_dkvar, double scale) {
   const long total = (dedup ? Nc : (long)S * Nc) * Dy;
   if (total == 0) return hipSuccess;
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(gauss_lik_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mean, var, Y, y_row0, Nc, S, dedup, Dy,
-                     lik_var, acc_elbo, acc_dlik, mbar, vbar, acc_dkvar);
+                     lik_var, acc_elbo, acc_dlik, mbar, vbar, acc_dkvar, scale);
   LAUNCH_CHECK();
 }
 

@@ -19,7 +19,7 @@ DGP_OK, ERR_INVALID, ERR_HIP, ERR_NOT_PD, ERR_NO_DEVICE, ERR_NONFINITE = 0, -1, 
 # every symbol include/dgp_abi.h declares
 SYMBOLS = [
     "dgp_create", "dgp_destroy", "dgp_last_error", "dgp_sync", "dgp_device_info", "dgp_model_set", "dgp_param_count",
-    "dgp_params_get", "dgp_params_set", "dgp_data_set", "dgp_set_workspace_limit", "dgp_elbo", "dgp_propagate",
+    "dgp_params_get", "dgp_params_set", "dgp_data_set", "dgp_set_workspace_limit", "dgp_batch_set", "dgp_elbo", "dgp_propagate",
     "dgp_propagate_vjp", "dgp_vjp_accumulate", "dgp_propagate_full_cov", "dgp_gpr_lml", "dgp_gpr_predict", "dgp_gpr_predict_vjp",
     "dgp_grad_partial", "dgp_acc_info", "dgp_acc_bind", "dgp_grad_finish", "dgp_grad_get", "dgp_last_elbo",
     "dgp_adam_reset", "dgp_adam_step", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_dev_gemm",
@@ -74,6 +74,7 @@ def load():
         "dgp_params_set": (C.c_int, [vp, _dp]),
         "dgp_data_set": (C.c_int, [vp, _dp, _dp, i64, i32, i32, i64]),
         "dgp_set_workspace_limit": (C.c_int, [vp, i64]),
+        "dgp_batch_set": (C.c_int, [vp, i64, i64, dbl]),
         "dgp_elbo": (C.c_int, [vp, i32, u64, _dpp, _dp, _dp]),
         "dgp_propagate": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dpp, _dpp, _dpp, i32]),
         "dgp_propagate_vjp": (C.c_int, [vp, _dp, i64, i32, u64, _dpp, _dp, _dp, _dp, _dp]),
@@ -179,6 +180,11 @@ class Context:
         X, Y = _c(X), _c(Y)
         self._chk(self._lib.dgp_data_set(self._h, _ptr(X), _ptr(Y), X.shape[0], X.shape[1], Y.shape[1],
                                          int(n_global_offset)))
+
+    def batch_set(self, start=0, count=0, scale=1.0):
+        """Evaluate the bound on the resident points [start, start+count) with the data term times `scale`
+        (count == 0: all points)."""
+        self._chk(self._lib.dgp_batch_set(self._h, int(start), int(count), float(scale)))
 
     def set_workspace_limit(self, nbytes):
         self._chk(self._lib.dgp_set_workspace_limit(self._h, int(nbytes)))

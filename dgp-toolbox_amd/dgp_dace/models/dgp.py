@@ -29,9 +29,15 @@ from ..utils.utils import BroadcastingLikelihood
 class DGP_Base:
     """The base class for deep GP models: Monte-Carlo variational bound and convenience functions."""
 
-    def __init__(self, likelihood, layers, num_samples=1, seed=0, device=None, **kwargs):
+    def __init__(self, likelihood, layers, num_samples=1, seed=0, device=None, minibatch_size=None, **kwargs):
         self.name = "dgp"
         self.num_samples = num_samples
+        # None: full batch, as every caller of the reference runs it (dgp.py:95-99 has scale == 1).  An integer B makes the
+        # training loops estimate the bound on B points per iteration (all ranks together) times N / B: the points are
+        # shuffled once at upload and visited in consecutive windows (C-ABI dgp_batch_set).
+        self.minibatch_size = minibatch_size
+        self._batch_pos = 0
+        self._n_local = self._n_total = 0
         self.likelihood = BroadcastingLikelihood(likelihood_from_any(likelihood))
         self.layers = layers
         self.seed = int(seed)
@@ -114,16 +120,33 @@ class DGP_Base:
 
     def _sync_data(self, data):
         X, Y = data
-        key = (id(X), id(Y), np.shape(X), np.shape(Y))
+        shuffled = self.minibatch_size is not None
+        key = (id(X), id(Y), np.shape(X), np.shape(Y), shuffled)
         if key != self._data_key:
             X = np.ascontiguousarray(X.numpy() if hasattr(X, "numpy") else X, dtype=np.float64)
             Y = np.ascontiguousarray(Y.numpy() if hasattr(Y, "numpy") else Y, dtype=np.float64)
             if X.ndim != 2 or Y.ndim != 2 or X.shape[0] != Y.shape[0]:
                 raise Exception("data must be (X [N, D], Y [N, D_y])")
+            if shuffled:          # consecutive windows of a fixed random order = minibatches without replacement
+                perm = np.random.default_rng(self.seed).permutation(X.shape[0])      # the same on every rank
+                X, Y = X[perm], Y[perm]
             lo, hi = (self._dist.shard(X.shape[0]) if self._dist else (0, X.shape[0]))
             self._ctx.data_set(X[lo:hi], Y[lo:hi], n_global_offset=lo)
+            self._n_local, self._n_total, self._batch_pos = hi - lo, X.shape[0], 0
             self._data_key = key
             self._keepalive = data
+
+    def _select_batch(self, ctx, minibatch):
+        """Full batch, or the next window of the shuffled resident points with the data term scaled by N / B."""
+        if not minibatch or self.minibatch_size is None:
+            ctx.batch_set(0, 0, 1.0)
+            return
+        world = self._dist.world if self._dist else 1
+        b = max(1, min(self._n_local, int(self.minibatch_size) // world))
+        if self._batch_pos + b > self._n_local:
+            self._batch_pos = 0
+        ctx.batch_set(self._batch_pos, b, self._n_total / float(b * world))
+        self._batch_pos += b
 
     def _next_seed(self):
         s = self.seed + self._eval_count
@@ -189,6 +212,7 @@ class DGP_Base:
         """Evidence lower bound: sum_n E_q[log p(y_n | f_n)] - sum_l KL_l   (dgp.py:89-100, scale == 1)."""
         ctx = self._sync_model()
         self._sync_data(data)
+        self._select_batch(ctx, False)
         L, KL = ctx.elbo(self.num_samples, self._next_seed(), None)
         if self._dist:
             L = self._dist.all_reduce_scalar(L, ctx.device)
@@ -202,6 +226,7 @@ class DGP_Base:
         """One ELBO evaluation with fresh normals + its gradient, left on the device."""
         ctx = self._sync_model()
         self._sync_data(data)
+        self._select_batch(ctx, True)
         ctx.grad_partial(self.num_samples, self._next_seed(), None)
         if self._dist:
             self._dist.all_reduce_(self._acc_tensor)

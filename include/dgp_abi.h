@@ -82,6 +82,12 @@ int dgp_params_set(dgp_ctx* ctx, const double* flat_in);   /* Parameter.assign()
 int dgp_data_set(dgp_ctx* ctx, const double* X, const double* Y, int64_t N, int32_t D, int32_t Dy,
                  int64_t n_global_offset);
 int dgp_set_workspace_limit(dgp_ctx* ctx, int64_t bytes);  /* bound on per-chunk intermediates in HBM */
+/* Minibatch estimate of the bound: dgp_elbo / dgp_grad_partial visit only the resident points [start, start+count)
+ * and multiply the data term (and its gradients) by `scale` (= N / batch size).  The reference computes
+ * `scale = num_data / batch size` but always feeds the full set (dgp.py:95-99; `minibatch_size` is stored and never
+ * used, MF_DGP.py:88), so this is the `num_data=` extension SURVEY App. A asks for.  count == 0: all points.
+ * dgp_data_set resets it to (0, 0, 1.0).  The Monte-Carlo normals stay keyed by the global point index.           */
+int dgp_batch_set(dgp_ctx* ctx, int64_t start, int64_t count, double scale);
 
 /* ---- forward: replaces DGP_Base.ELBO / ELBO_closure (dgp.py:89-109).
  * zs: NULL (draw N(0,1) from Philox4x32-10 keyed by seed) or n_layers host pointers [S,N,D_out_l]

@@ -191,6 +191,62 @@ def test_medium_size_against_oracle():
             assert np.abs(Gp[(i, k)] - ref).max() < 1e-6 * max(1.0, np.abs(ref).max()), (i, k)
 
 
+@pytest.mark.parametrize("case", CASES[:2])
+def test_minibatch_window_and_scale(case):
+    """dgp_batch_set: the bound and its gradient on a window of the resident points with the data term times N / B
+    equal the restatement evaluated on that window repeated `scale` times (scale = 3)."""
+    import dgp_oracle_torch as T
+    g = load(case)
+    m = product_from_golden(g)
+    mo = oracle_from_golden(g)
+    nl, S = n_layers(g), int(g["S"])
+    zs = [g[f"zs{i}"] for i in range(nl)]
+    N = g["X"].shape[0]
+    lo, cnt = N // 4, N // 3
+    ctx = m._sync_model()
+    m._sync_data(m.data)
+    ctx.batch_set(lo, cnt, 3.0)
+    L, KL = ctx.elbo(S, 0, zs)
+    ctx.grad_partial(S, 0, zs)
+    elbo = ctx.grad_finish(want_elbo=True)
+    sl = slice(lo, lo + cnt)
+    X3, Y3 = np.tile(g["X"][sl], (3, 1)), np.tile(g["Y"][sl], (3, 1))
+    eo, G = T.elbo_and_grads(mo, [np.tile(z[:, sl], (1, 3, 1)) for z in zs], S=S, data=(X3, Y3))
+    assert abs(elbo - eo) < 1e-9 * abs(eo) and abs((L - KL) - eo) < 1e-9 * abs(eo)
+    Gp = split_flat(m, ctx.grad_get())
+    for i in range(nl):
+        for k in ("Z", "variance", "lengthscales", "q_mu", "q_sqrt"):
+            ref = G["layers"][i][k]
+            assert np.abs(Gp[(i, k)] - ref).max() < 2e-8 * max(1.0, np.abs(ref).max()), (i, k)
+    assert abs(Gp[("lik", "variance")] - G["lik_variance"]) < 1e-8 * max(1.0, abs(G["lik_variance"]))
+    ctx.batch_set(0, 0, 1.0)                       # back to the full set: the golden value
+    L, KL = ctx.elbo(S, 0, zs)
+    assert abs((L - KL) - g["elbo"]) < 1e-9 * abs(g["elbo"])
+
+
+def test_minibatch_training_loop(capsys):
+    """optimize_adam / optimize_nat_adam with minibatch_size: windows of the shuffled data, scaled estimates, and a
+    full-data bound that improves."""
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    rng = np.random.default_rng(1)
+    N = 400
+    X = rng.uniform(-1, 1, (N, 2)); Y = np.sin(3 * X[:, :1]) * X[:, 1:] + 0.05 * rng.standard_normal((N, 1))
+    m = DGP(X, Y, X[:20].copy(), [RBF(1.0, [1.0, 1.0]) for _ in range(2)], [2], Gaussian(), num_samples=5, minibatch_size=64)
+    from dgp_dace.models.dgp import DGP_Base
+    for l in m.layers[:-1]:
+        l.q_sqrt.assign(l.q_sqrt * 1e-2)
+    e0 = m.ELBO()
+    DGP_Base.optimize_adam(m, m.data, iterations=60, lr=0.02, messages=20)      # (the variant without the q_sqrt rescaling)
+    assert m._n_local == N and 0 < m._batch_pos <= N
+    assert m.ELBO() > e0
+    m.optimize_nat_adam(iterations1=5, iterations2=20, messages=10)
+    trace = [float(l.split(":")[1]) for l in capsys.readouterr().out.splitlines() if l.startswith("ELBO")]
+    assert len(trace) == 3 + 1 + 2 and np.all(np.isfinite(trace))
+    mean, var = m.predict(X[:7], 10)
+    assert mean.shape == (7, 1) and np.all(var > 0)
+
+
 def test_empty_prediction_set():
     """No points in, empty [S, 0, D] arrays out (what the reference's TensorFlow ops return for N = 0)."""
     from helpers import load, product_from_golden
