@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--M", type=int, default=256)
     ap.add_argument("--S", type=int, default=10)
     ap.add_argument("--num-units", type=str, default="8,8")
+    ap.add_argument("--minibatch", type=int, default=0,
+                    help="points per iteration over all ranks (0 = full batch, the headline configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8192)
     args = ap.parse_args()
@@ -128,7 +130,7 @@ def main():
     stdout = sys.stdout
     sys.stdout = open(os.devnull, "w")          # the constructor prints the architecture (as the reference does)
     model = DGP(X, Y, Z, [RBF(variance=1.0, lengthscales=[1.0] * d) for d in dims], num_units, Gaussian(),
-                num_samples=args.S, seed=0, device=local_rank)
+                num_samples=args.S, seed=0, device=local_rank, minibatch_size=args.minibatch or None)
     sys.stdout = stdout
     for layer in model.layers[:-1]:
         layer.q_sqrt.assign(layer.q_sqrt * 1e-3)      # dgp.py:268-269, what optimize_adam does first
@@ -185,7 +187,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"DGP num_units={num_units} ({len(num_units) + 1} SVGP layers), N={args.N}, "
-                                   f"D={args.D}, M={args.M}, S={args.S}, full batch, optimize_adam iteration",
+                                   f"D={args.D}, M={args.M}, S={args.S}, " + (f"minibatch {args.minibatch}" if args.minibatch else "full batch") + ", optimize_adam iteration",
                        "N": args.N, "D": args.D, "M": args.M, "S": args.S, "num_units": num_units,
                        "parallelism": f"data points sharded over {world} GPU(s), one all-reduce per iteration"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -193,12 +195,12 @@ def main():
                          "kernel": "dgp::gemm_f64_kernel (all point contractions, rank 0)",
                          "kernel_ms_per_step": mf["ms"] / args.steps, "launches_per_step": mf["launches"] / args.steps,
                          "alg_flops_per_step_rank0": mf["alg_flops"] / args.steps,
-                         "whole_step_frac": alg_flops_step(args.N, args.S, dims, args.M, 1) / world / (dt / args.steps)
+                         "whole_step_frac": alg_flops_step(args.minibatch or args.N, args.S, dims, args.M, 1) / world / (dt / args.steps)
                                             / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                         "frac_by_survey_8d_per_unit_figure": survey_per_unit_flops_step(args.N, args.S, dims, args.M, 1)
+                         "frac_by_survey_8d_per_unit_figure": survey_per_unit_flops_step(args.minibatch or args.N, args.S, dims, args.M, 1)
                                                               / world / (mf["ms"] / args.steps * 1e-3) / 1e12
                                                               / FP64_MFMA_PEAK_TFLOPS,
-                         "whole_step_frac_by_survey_8d_count": survey_flops_step(args.N, args.S, dims, args.M, 1) / world
+                         "whole_step_frac_by_survey_8d_count": survey_flops_step(args.minibatch or args.N, args.S, dims, args.M, 1) / world
                                                                / (dt / args.steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
             "breakdown_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
             "elbo_last": elbo_last, "device": name,
