@@ -413,3 +413,32 @@ def test_mf_oracle_autograd_against_finite_differences():
            "ws_proj": [[np.concatenate([w, w], 1) for w in nm["ws_proj"][0]]]}
     _, parts2, _ = mo.elbo_and_grads(P2, X2, [Y[0], np.concatenate([Y[1], Y[1]])], [np.concatenate([X_red[0], X_red[0]])], nm2, S)
     assert abs(parts2["L_red"] - 4.0 * parts["L_red"]) <= 1e-9 * abs(parts["L_red"])      # 2x the points, 2x the scale
+
+
+def test_utils_surface_reparameterize_and_broadcasting_likelihood():
+    """Callable surface of utils.py:22-117 (element-wise helpers on arrays; the models evaluate these inside kernels)."""
+    from dgp_dace.gpflow_compat import Gaussian
+    from dgp_dace.utils.utils import BroadcastingLikelihood, reparameterize
+    rng = np.random.default_rng(0)
+    S, N, D = 3, 5, 2
+    mean, z = rng.standard_normal((S, N, D)), rng.standard_normal((S, N, D))
+    var = rng.uniform(0.1, 1.0, (S, N, D))
+    np.testing.assert_allclose(reparameterize(mean, var, z), mean + z * np.sqrt(var + 1e-6), rtol=1e-15)
+    assert reparameterize(mean, None, z) is mean
+    A = rng.standard_normal((S, D, N, N))
+    full = np.transpose(A @ np.transpose(A, (0, 1, 3, 2)) + 0.1 * np.eye(N), (0, 2, 3, 1))            # S,N,N,D
+    f = reparameterize(mean, full, z, full_cov=True)
+    for s in range(S):
+        for d in range(D):
+            Lc = np.linalg.cholesky(full[s, :, :, d] + 1e-6 * np.eye(N))
+            np.testing.assert_allclose(f[s, :, d], mean[s, :, d] + Lc @ z[s, :, d], rtol=1e-12, atol=1e-12)
+    lik = BroadcastingLikelihood(Gaussian(variance=0.3))
+    Y = rng.standard_normal((N, D))
+    m = O.OracleDGP(*notebook_data(), [O.RBF(), O.RBF(), O.RBF()], [1, 1], lik_variance=0.3)
+    np.testing.assert_allclose(lik.variational_expectations(mean, var, Y), m.variational_expectations(mean, var, Y), rtol=1e-14)
+    mu, v = lik.predict_mean_and_var(mean, var)
+    np.testing.assert_allclose(v, var + 0.3, rtol=1e-15); np.testing.assert_allclose(mu, mean)
+    np.testing.assert_allclose(lik.logp(mean, Y), lik.variational_expectations(mean, 0 * var, Y), rtol=1e-14)
+    np.testing.assert_allclose(lik.predict_density(mean, var, Y), -0.5 * np.log(2 * np.pi * (var + 0.3)) - 0.5 * (Y[None] - mean) ** 2 / (var + 0.3))
+    assert lik.conditional_variance(mean).shape == (S, N, D) and np.allclose(lik.conditional_variance(mean), 0.3)
+    assert lik.needs_broadcasting is False
