@@ -426,6 +426,20 @@ class DGP_Base:
         Fmean, Fvar = self.predict_f(Xnew, full_cov=full_cov, S=num_samples)
         return Fmean, as_tensor(Fvar + float(self.likelihood.likelihood.variance._value))
 
+    def _likelihood_at_fidelity(self, Fmu, Fvar, Y, variance):
+        """Gaussian log-likelihood term of one fidelity (MF_DGP_EM.py:205-216)."""
+        return as_tensor(_ve(np.asarray(Fmu), np.asarray(Fvar), np.asarray(Y, dtype=np.float64), float(variance)))
+
+    def E_log_p_Y(self, X_f, Y_f, fidelity=None, fidelity_dim=None, project=False):
+        """Expected data log-likelihood per point, averaged over the Monte-Carlo samples (MF_DGP_EM.py:218-260): [N, D]."""
+        if project:
+            mean, var = self.project(X_f, S=self.num_samples, fidelity=fidelity, fidelity_dim=fidelity_dim)
+            s2 = float(self.likelihood_projection.likelihood.variance._value)
+        else:
+            mean, var = self.predict_f(X_f, S=self.num_samples, fidelity=fidelity, fidelity_dim=fidelity_dim)
+            s2 = self._noise(self.num_layers - 1 if fidelity is None or fidelity == -1 else fidelity)[0]
+        return as_tensor(np.mean(_ve(np.asarray(mean), np.asarray(var), np.asarray(Y_f, dtype=np.float64), s2), 0))
+
     def predict_density(self, Xnew, Ynew, num_samples):
         """log of the mixture predictive density, averaged over the samples (MF_DGP_EM.py:318-322)."""
         Fmean, Fvar = self.predict_f(Xnew, full_cov=False, S=num_samples)

@@ -190,6 +190,11 @@ def test_mf_dgp_em_training_phases_and_prediction(capsys):
         assert np.sqrt(np.mean((mean - hf(Xt)) ** 2)) < np.std(Y[1])
         dens = mf.model.predict_density(Xt, hf(Xt), 20)
         assert dens.shape == (20, 1) and np.all(np.isfinite(dens))
+        e_top = mf.model.E_log_p_Y(X[1], Y[1], fidelity=1, fidelity_dim=1)
+        e_low = mf.model.E_log_p_Y(X[0], Y[0], fidelity=0, fidelity_dim=0)
+        e_prj = mf.model.E_log_p_Y(X[1], X_red[0], fidelity=0, fidelity_dim=1, project=True)
+        assert e_top.shape == (10, 1) and e_low.shape == (30, 1) and e_prj.shape == (10, 2)
+        assert all(np.all(np.isfinite(e)) for e in (e_top, e_low, e_prj))
 
 
 def test_more_than_1024_inducing_points():
