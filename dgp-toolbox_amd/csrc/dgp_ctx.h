@@ -99,11 +99,13 @@ struct dgp_ctx {
   hipStream_t side[kSide] = {nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr};
   bool use_side = true;
-  // Option (DGP_STORE_T=1): keep t_d = W_d^T c from the forward pass (16 KB/point/layer at D=8, M=256), so that dC
-  // needs only the triangular products W_d t_d instead of the dense S'_d c.  Measured at config 2: the dC product
-  // 19.2 -> 15.7 ms (it now streams 16 GB, re-read per column tile), the T-product 12.0 -> 15.1 ms (the 16 GB store):
-  // no net gain, +32 GB of HBM traffic per iteration -> off by default.
-  bool store_t = false;
+  // Keep t_d = W_d^T c from the forward pass (16 KB/point/layer at D=8, M=256) so that dC needs only the triangular
+  // products W_d t_d instead of the dense S'_d c (DGP_STORE_T=0 selects the T-free form).  History at config 2: when
+  // the triangular products ran at tile granularity this was a wash (dC 19.2 -> 15.7 ms against the T-product's
+  // 12.0 -> 15.1 ms for the 16 GB store); with the half-MFMA diagonal k-tiles both products of this form got
+  // cheaper and it wins everywhere measured (config 2: 69.9 -> 67.1 ms, config 4 minibatch 86.8 -> 77.6 ms, config 4
+  // shard 1810 -> 1656 ms, N/8 shard -0.2 ms) at +32 GB of HBM traffic per iteration and 16 GB more workspace.
+  bool store_t = true;
   std::vector<double*> zs_dev;
   std::vector<size_t> zs_cap;
   double* Xnew = nullptr;

@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     // with both of its blocks, so nothing is gained there).  10 % of the MFMA work of an M = 256 triangular product.
     // Handled as separate phases before / after the main loop (single triangular block only), not as a branch
     // inside it: a three-way dispatch per k-tile made hipcc spill ~400 VGPRs in every instantiation.
-    const int tri_sk = (FN != 2 || WC != 2 || !tri_ok || !g.tri_half || nkb != 1 || khi - klo < 4 * BK || (ktiles & 1)) ? 0
+    const int tri_sk = (FN != 2 || WC != 2 || !tri_ok || !g.tri_half || khi - klo < 4 * BK || (ktiles_per_blk & 1)) ? 0
                        : (g.tri == TRI_B_UPPER ? 1 : (g.tri == TRI_B_LOWER ? 2 : 0));
     auto pair = [&](auto sk, long kt) {
 #ifndef DGP_ABLATE_GLOBAL
@@ -579,11 +579,16 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       // inside the general kernel made hipcc spill.
       for (long kt = 0; kt < ktiles; kt += 2) pair(integral_constant<int, 3>{}, kt);
     } else {
-      long kt = 0;
-      if (tri_sk == 2) { pair(integral_constant<int, 2>{}, 0); kt = 2; }
-      const long kt_end = tri_sk == 1 ? ktiles - 2 : ktiles;
-      for (; kt < kt_end; kt += 2) pair(SK0, kt);
-      if (tri_sk == 1) pair(integral_constant<int, 1>{}, ktiles - 2);
+      // one pass per triangular block (a single one for the K = Mp products; D of them when K spans the d-blocks)
+      const long nblk_run = tri_sk ? nkb : 1, per_run = tri_sk ? ktiles_per_blk : ktiles;
+      for (long kb = 0; kb < nblk_run; ++kb) {
+        long kt = kb * per_run;
+        const long kt_last = kt + per_run;
+        if (tri_sk == 2) { pair(integral_constant<int, 2>{}, kt); kt += 2; }
+        const long kt_end = tri_sk == 1 ? kt_last - 2 : kt_last;
+        for (; kt < kt_end; kt += 2) pair(SK0, kt);
+        if (tri_sk == 1) pair(integral_constant<int, 1>{}, kt_last - 2);
+      }
     }
   }
 

@@ -583,8 +583,9 @@ def test_infill_optimize_de_then_adam_improves_the_criterion():
 
 
 def test_stored_t_formulation_gives_the_same_gradient(monkeypatch):
-    """DGP_STORE_T=1 keeps t_d = W_d^T c from the forward pass and forms dC from triangular products (non-wrapping
-    scaled A operand, per-block triangular k-ranges, "- c" epilogue term of the GEMM engine): same gradient."""
+    """The default keeps t_d = W_d^T c from the forward pass and forms dC from triangular products (non-wrapping
+    scaled A operand, per-block triangular k-ranges, "- c" epilogue term of the GEMM engine); DGP_STORE_T=0 selects
+    the T-free form with the dense S'_d product: same gradient."""
     g = load(CASES[1])
     nl = n_layers(g)
     zs = [g[f"zs{i}"] for i in range(nl)]
