@@ -171,8 +171,22 @@ _KERNEL_CLASSES = {"SquaredExponential": SquaredExponential, "RBF": SquaredExpon
                    "Matern52": Matern52}
 
 
+def split_white(kern):
+    """(stationary kernel, White kernel or None) of `k` or `k + White(...)` - the two forms a DGP layer kernel may take."""
+    if isinstance(kern, Sum):
+        base = [k for k in kern.kernels if not isinstance(k, White)]
+        white = [k for k in kern.kernels if isinstance(k, White)]
+        if len(base) == 1 and len(white) == 1 and isinstance(base[0], SquaredExponential):
+            return base[0], white[0]
+        raise NotImplementedError("layer kernel: a stationary kernel, optionally plus one White kernel")
+    return kern, None
+
+
 def kernel_matrix_host(kern, Z):
     """K(Z, Z) in NumPy for the constructor-time prior initialisation (layers.py:220-223 does this on the host too)."""
+    kern, white = split_white(kern)
+    if white is not None:
+        return kernel_matrix_host(kern, Z) + float(white.variance._value) * np.eye(Z.shape[0])
     Zs = Z / kern.lengthscales._value
     sq = np.sum(Zs * Zs, -1)
     r2 = -2.0 * Zs @ Zs.T + sq[:, None] + sq[None, :]
@@ -236,7 +250,14 @@ def kernel_from_any(k, input_dim):
         if k.lengthscales.shape == (1,) and input_dim > 1:       # isotropic -> ARD storage
             k.lengthscales = Parameter(np.full(input_dim, k.lengthscales._value[0]), "lengthscales", "softplus")
         return k
+    if isinstance(k, White):
+        return k
     name = type(k).__name__
+    if name == "Sum" and hasattr(k, "kernels"):                   # stationary + White (ours or gpflow's)
+        out = Sum([White(variance=_val(q.variance)) if type(q).__name__ == "White" and not isinstance(q, White)
+                   else kernel_from_any(q, input_dim) for q in k.kernels])
+        split_white(out)
+        return out
     if name not in _KERNEL_CLASSES:
         raise NotImplementedError(
             f"kernel {name}: the HIP path implements the stationary kernels the reference's DGP callers use "

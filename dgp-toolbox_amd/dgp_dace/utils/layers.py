@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from ..gpflow_compat import KERNEL_KINDS, Parameter, as_tensor, kernel_matrix_host
+from ..gpflow_compat import KERNEL_KINDS, Parameter, as_tensor, kernel_matrix_host, split_white
 
 JITTER = 1e-6      # gpflow.default_jitter() (layers.py:222)
 MEAN_KINDS = {"zero": 0, "identity": 1, "linear": 2}
@@ -60,12 +60,15 @@ class SVGP_Layer(Layer):
         return self.feature.Z.shape[1]
 
     def desc(self):
+        base, white = split_white(self.kern)
         return (self.input_dim, self.num_outputs, self.num_inducing, 1 if self.white else 0,
-                KERNEL_KINDS[self.kern.kind], MEAN_KINDS[self.mean_function.kind])
+                KERNEL_KINDS[base.kind], MEAN_KINDS[self.mean_function.kind], 0 if white is None else 1)
 
     def parameters(self):
-        """[Z, variance, lengthscales, q_mu, q_sqrt] — the packing order of dgp_model_set."""
-        return [self.feature.Z, self.kern.variance, self.kern.lengthscales, self.q_mu, self.q_sqrt]
+        """[Z, variance, lengthscales, (white.variance,) q_mu, q_sqrt] — the packing order of dgp_model_set."""
+        base, white = split_white(self.kern)
+        return [self.feature.Z, base.variance, base.lengthscales] + ([] if white is None else [white.variance]) + \
+               [self.q_mu, self.q_sqrt]
 
     def mean_params(self):
         if self.mean_function.kind != "linear":

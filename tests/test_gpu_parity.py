@@ -902,3 +902,52 @@ def test_bench_py_multi_rank_launch_over_gloo(tmp_path):
         assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and "workload" in d["config"]
         assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1) < 1e-9
     assert abs(d1["elbo_last"] - d2["elbo_last"]) < 1e-10 * abs(d1["elbo_last"])
+
+
+def test_stationary_plus_white_kernel_in_a_dgp_layer():
+    """`k + White(variance)` as a layer kernel of the ordinary DGP (the reference accepts any GPflow kernel; the
+    multi-fidelity models add White to every layer but the last, MF_DGP_EM.py:364-367): with variance 0 the bound and
+    the gradient are those of the plain kernel; the White variance's own gradient matches a central difference."""
+    from dgp_dace.gpflow_compat import RBF, Matern32, White, Gaussian
+    from dgp_dace.models.dgp import DGP
+    rng = np.random.default_rng(3)
+    N, D, M, S = 60, 2, 12, 3
+    X = rng.uniform(-1, 1, (N, D)); Y = np.sin(2 * X[:, :1]) + 0.1 * rng.standard_normal((N, 1))
+    Z = X[:M].copy()
+    zs = [rng.standard_normal((S, N, 2)), rng.standard_normal((S, N, 1))]
+
+    def build(w):
+        ks = [RBF(1.1, [0.8, 1.2]), Matern32(0.9, [1.0, 0.7])]
+        if w is not None:
+            ks = [ks[0] + White(variance=w), ks[1] + White(variance=w)]
+        m = DGP(X, Y, Z, ks, [2], Gaussian(variance=0.5), num_samples=S)
+        for l in m.layers:
+            l.q_mu.assign(0.3 * np.ones(l.q_mu.shape)); l.q_sqrt.assign(0.5 * np.tile(np.eye(M)[None], [l.num_outputs, 1, 1]))
+        ctx = m._sync_model(); m._sync_data(m.data)
+        ctx.grad_partial(S, 0, zs)
+        return m, ctx, ctx.grad_finish(want_elbo=True), ctx.grad_get()
+
+    _, _, e_plain, g_plain = build(None)
+    m0, _, e0, g0 = build(0.0)
+    assert abs(e0 - e_plain) <= 1e-12 * abs(e_plain)
+    assert m0.number_parameters(False) == build(None)[0].number_parameters(False) + 2
+    # drop the two white entries of the flat gradient and compare with the plain model
+    offs, off = [], 0
+    for l in m0.layers:
+        for p in l.parameters():
+            if p.name == "variance" and p is not l.parameters()[1]:
+                offs.append(off)
+            off += p._value.size
+    keep = np.ones(g0.size, bool); keep[offs] = False
+    np.testing.assert_allclose(g0[keep], g_plain, rtol=1e-10, atol=1e-10)
+    h = 1e-5
+    for k, o in enumerate(offs):
+        def at(w):
+            m, ctx, e, _ = build(0.02)
+            from dgp_dace.gpflow_compat import split_white
+            split_white(m.layers[k].kern)[1].variance.assign(w)
+            ctx = m._sync_model(); ctx.grad_partial(S, 0, zs)
+            return ctx.grad_finish(want_elbo=True), ctx.grad_get()
+        (ep, _), (em, _), (_, gc) = at(0.02 + h), at(0.02 - h), at(0.02)
+        fd = (ep - em) / (2 * h)
+        assert abs(gc[o] - fd) <= 1e-5 * max(1.0, abs(fd)), (k, gc[o], fd)
