@@ -21,8 +21,8 @@ struct GprFit {
 // K0 = K(X,X) + 1e-6 I (shared kernel, jitter removed again below), L = chol(K(X,X) + noise I), Linv, A = L^-1 Y
 int gpr_fit(dgp_ctx* ctx, GprFit& f, int kind, const double* X, const double* Y, long N, int D, int Dy, double variance,
             const double* ls, double noise) {
-  if (!X || !Y || !ls || N <= 0 || N > 1024 || D <= 0 || D > 64 || Dy <= 0 || kind < DGP_KERNEL_RBF || kind > DGP_KERNEL_MATERN52)
-    return fail(ctx, DGP_ERR_INVALID, "gpr: bad arguments (1 <= N <= 1024, 1 <= D <= 64)");
+  if (!X || !Y || !ls || N <= 0 || N > 4096 || D <= 0 || D > 64 || Dy <= 0 || kind < DGP_KERNEL_RBF || kind > DGP_KERNEL_MATERN52)
+    return fail(ctx, DGP_ERR_INVALID, "gpr: bad arguments (1 <= N <= 4096, 1 <= D <= 64)");
   HIPCHK(hipSetDevice(ctx->device));
   const int Np = (int)round_up(N, 64);
   const long NN = (long)Np * Np;

@@ -951,3 +951,28 @@ def test_stationary_plus_white_kernel_in_a_dgp_layer():
         (ep, _), (em, _), (_, gc) = at(0.02 + h), at(0.02 - h), at(0.02)
         fd = (ep - em) / (2 * h)
         assert abs(gc[o] - fd) <= 1e-5 * max(1.0, abs(fd)), (k, gc[o], fd)
+
+
+def test_exact_gp_regression_beyond_1024_points():
+    """The exact GP (SO_BO's num_layers == 0 surrogate) past N = 1024: N = 1300 (padded to 1344), marginal likelihood,
+    its gradient and the prediction against the restatement."""
+    import gpr_oracle as G
+    from dgp_dace.gpflow_compat import RBF
+    from dgp_dace.models.gpr import GPR
+    rng = np.random.default_rng(8)
+    N, D = 1300, 2
+    X, Xs = rng.uniform(-1, 1, (N, D)), rng.uniform(-1, 1, (9, D))
+    Y = np.sin(3 * X[:, :1]) * X[:, 1:] + 0.05 * rng.standard_normal((N, 1))
+    ls, var, noise = np.array([0.4, 0.6]), 1.1, 1e-2
+    m = GPR((X, Y), RBF(var, ls), noise_variance=noise)
+    ok = O.RBF(var, ls)
+    want = G.log_marginal_likelihood(ok, X, Y, noise)
+    assert abs(m.log_marginal_likelihood() - want) < 1e-8 * abs(want)
+    _, g = m.loss_and_grad()
+    _, gv, gl, gn = G.lml_and_grads(ok, X, Y, noise)
+    want_g = -np.concatenate([[gv], gl, [gn]])
+    _close(g, want_g, rtol=0, atol=1e-6 * np.abs(want_g).max())
+    mean, v = m.predict_y(Xs)
+    omean, ov = G.predict_y(ok, X, Y, noise, Xs)
+    _close(mean, omean, rtol=1e-6, atol=1e-8)
+    _close(v, ov, rtol=1e-5, atol=1e-8)
