@@ -128,7 +128,7 @@ int dgp_vjp_accumulate(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, 
                        int32_t reset);
 
 /* ---- exact GP regression: replaces gpflow.models.GPR as SO_BO builds it for num_layers == 0 (SO_BO.py:187-200,
- *      training :252-256, prediction through Infill_criteria.py:28-35).  Stateless (needs only dgp_create), N <= 1024.
+ *      training :252-256, prediction through Infill_criteria.py:28-35).  Stateless (needs only dgp_create), N <= 4096.
  *   dgp_gpr_lml     : log marginal likelihood  sum_d log N(Y_d | 0, K(X,X) + noise I)  and, if grad_out != NULL, its
  *                     derivatives w.r.t. the constrained hyper-parameters: grad_out[0] variance, [1..D] lengthscales,
  *                     [1+D] noise variance  (what tape.gradient(training_loss, trainable_variables) yields, negated)
