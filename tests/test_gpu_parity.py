@@ -976,3 +976,23 @@ def test_exact_gp_regression_beyond_1024_points():
     omean, ov = G.predict_y(ok, X, Y, noise, Xs)
     _close(mean, omean, rtol=1e-6, atol=1e-8)
     _close(v, ov, rtol=1e-5, atol=1e-8)
+
+
+def test_numerical_failures_surface_as_exceptions():
+    """Where TensorFlow raises InvalidArgumentError from the Cholesky or lets NaN through, the engine raises:
+    a kernel variance that makes Kuu indefinite -> NotPositiveDefinite; NaN targets -> a non-finite-ELBO error; and
+    the model stays usable after the bad value is repaired."""
+    from dgp_dace._native import NativeError, NotPositiveDefinite
+    m = product_from_golden(load(CASES[0]), seed=1)
+    e0 = m.ELBO()
+    m.layers[0].kern.variance.assign(-1.0)
+    with pytest.raises(NotPositiveDefinite):
+        m.ELBO()
+    m.layers[0].kern.variance.assign(1.0)
+    assert np.isfinite(m.ELBO())
+    X, Y = m.data
+    Ybad = Y.copy(); Ybad[3, 0] = np.nan
+    with pytest.raises(NativeError):
+        m.ELBO((X, Ybad))
+    assert np.isfinite(m.ELBO((X, Y)))
+    del e0
