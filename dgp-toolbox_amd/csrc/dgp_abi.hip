@@ -180,6 +180,7 @@ int dgp_params_set(dgp_ctx* ctx, const double* flat_in) {
   HIPCHK(hipMemcpyAsync(ctx->params, flat_in, ctx->n_params * 8, hipMemcpyHostToDevice, ctx->st));
   HIPCHK(hipStreamSynchronize(ctx->st));
   ctx->grad_ready = false;
+  ctx->prep_level = 0;
   return DGP_OK;
 }
 
@@ -576,6 +577,7 @@ int dgp_adam_step(dgp_ctx* ctx, double lr, double beta_1, double beta_2, double 
     HIPCHK(hipMemcpy(ctx->segs_dev, ctx->segs.data(), ctx->segs.size() * sizeof(ParamSeg), hipMemcpyHostToDevice));
     ctx->segs_uploaded = true;
   }
+  ctx->prep_level = 0;
   ctx->adam_t += 1;
   const double t = (double)ctx->adam_t;
   const double lr_t = lr * std::sqrt(1.0 - std::pow(beta_2, t)) / (1.0 - std::pow(beta_1, t));
@@ -587,6 +589,7 @@ int dgp_adam_step(dgp_ctx* ctx, double lr, double beta_1, double beta_2, double 
 
 int dgp_natgrad_step(dgp_ctx* ctx, double gamma, const uint8_t* layer_mask) {
   if (!ctx || !ctx->grad_ready) return fail(ctx, DGP_ERR_INVALID, "dgp_natgrad_step: no gradient (call dgp_grad_finish)");
+  ctx->prep_level = 0;
   LayerFork fork(ctx, (int)ctx->L.size());
   for (size_t l = 0; l < ctx->L.size(); ++l) {
     if (layer_mask && !layer_mask[l]) continue;

@@ -113,6 +113,10 @@ struct dgp_ctx {
   std::vector<double*> out_dev[3];
   std::vector<size_t> out_cap[3];
   bool grad_ready = false;
+  int prep_level = 0;      // what the small-matrix state on the device matches: 0 nothing, 1 forward pieces, 2 + backward pieces.
+                           // Parameters only change through model_set / params_set / adam_step / natgrad_step, so repeated
+                           // evaluations at fixed parameters (prediction sweeps of the acquisition side, the layer calls of
+                           // the multi-fidelity graph) factorise Kuu once.
   bool segs_uploaded = false;
   Prof prof;
 };
@@ -324,6 +328,7 @@ int grow(dgp_ctx* ctx, double** p, size_t* cap, size_t n) {
 }
 
 void free_model(dgp_ctx* ctx) {
+  ctx->prep_level = 0;
   for (auto& l : ctx->L) {
     dev_free(l.Kuu); dev_free(l.Lu); dev_free(l.Linv); dev_free(l.Lq); dev_free(l.qmu_p); dev_free(l.Wcat);
     dev_free(l.u); dev_free(l.Scat); dev_free(l.Z1); dev_free(l.Euu); dev_free(l.kdot); dev_free(l.dLq); dev_free(l.dqmu_p);
@@ -427,6 +432,11 @@ inline const double* P(dgp_ctx* ctx, long off) { return ctx->params + off; }
 
 // ------------------------------------------------------------------------------- prep: small matrices + KL
 int prep(dgp_ctx* ctx, bool train = false) {
+  if (ctx->prep_level >= (train ? 2 : 1)) {        // parameters unchanged: keep the factorisation and the KL in scal[0]
+    HIPCHK(hipMemsetAsync(ctx->scal + 1, 0, 3 * sizeof(double), ctx->st));
+    return DGP_OK;
+  }
+  ctx->prep_level = train ? 2 : 1;
   HIPCHK(hipMemsetAsync(ctx->scal, 0, 4 * sizeof(double), ctx->st));
   LayerFork fork(ctx, (int)ctx->L.size());
   for (size_t li = 0; li < ctx->L.size(); ++li) {
@@ -626,6 +636,7 @@ int check_flags(dgp_ctx* ctx) {
   HIPCHK(hipMemcpyAsync(&h, ctx->info, sizeof(int), hipMemcpyDeviceToHost, ctx->st));
   HIPCHK(hipStreamSynchronize(ctx->st));
   if (h) {
+    ctx->prep_level = 0;
     HIPCHK(hipMemsetAsync(ctx->info, 0, sizeof(int), ctx->st));
     return fail(ctx, DGP_ERR_NOT_PD, "Cholesky: matrix is not positive definite");
   }
