@@ -33,6 +33,8 @@ int dgp_create(int device, void* hip_stream, dgp_ctx** out) {
     ctx->use_side = !(e && e[0] == '0');
     const char* t = getenv("DGP_STORE_T");
     ctx->store_t = !(t && t[0] == '0');
+    const char* bt = getenv("DGP_BLOCKED_T");
+    ctx->blocked_t = !(bt && bt[0] == '0');
     bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < dgp_ctx::kSide && ok; ++i)
       ok = hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) == hipSuccess &&

@@ -106,6 +106,7 @@ struct dgp_ctx {
   // cheaper and it wins everywhere measured (config 2: 69.9 -> 67.1 ms, config 4 minibatch 86.8 -> 77.6 ms, config 4
   // shard 1810 -> 1656 ms, N/8 shard -0.2 ms) at +32 GB of HBM traffic per iteration and 16 GB more workspace.
   bool store_t = true;
+  bool blocked_t = true;   // t_d in the engine's blocked layout (gemm_f64.h: a_blocked / c_blocked); DGP_BLOCKED_T=0: row-major
   std::vector<double*> zs_dev;
   std::vector<size_t> zs_cap;
   double* Xnew = nullptr;
@@ -515,6 +516,7 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
     {  // t_d = W_d^T c: |t_d|^2 partials always leave the kernel; t_d itself only for the backward pass (store_t)
       GemmArgs a = mk(Pm, (long)D * Mp, Mp, y.Ct, Mp, y.Wcat, (long)D * Mp, y.Tt, (long)D * Mp);
       a.tri = TRI_B_LOWER; a.triblk = Mp; a.epi = y.Tt ? 2 : 1; a.rowsq = y.tnp; a.rowsq_ld = Pm;
+      a.c_blocked = (y.Tt && ctx->blocked_t) ? 1 : 0;      // t_d is read back only by the dC product below: blocked layout
       RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 8 * (y.Tt ? 1 + D : 1)));
     }
     RET(GX(ctx, 0, GEMM_NN, mk(Pm, D, Mp, y.Ct, Mp, y.u, D, y.mean0, D), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
@@ -556,6 +558,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     if (y.Tt) {  // dC = sum_d 2 vbar_d (W_d t_d - c): [2 vbar .* T] * WTcat, W_d lower => k <= n per block; "- c" in the epilogue
       GemmArgs a = mk(Pm, Mp, DM, y.Tt, DM, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);
       a.ascale = y.vbar; a.as_ld = D; a.a_kblk = Mp; a.ascale_mode = 1; a.a_wrap = 0;
+      a.a_blocked = ctx->blocked_t ? 1 : 0;
       a.tri = TRI_B_UPPER; a.triblk = Mp;
       a.eadd = y.Ct; a.eadd_nsc = D;
       a.rowf = y.mbar; a.colf = y.u; a.rank = D;             // + mbar u^T in the epilogue

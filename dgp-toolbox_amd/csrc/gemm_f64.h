@@ -63,6 +63,11 @@ struct GemmArgs {
   // TRI_OUT_LOWER launches: number of output tiles that survive the skip when the grid is COMPACT (only those
   // tiles are launched: early-exit workgroups were measured to cost as much as running ones); 0 = full grid
   int active_tiles = 0;
+  // Blocked layout of a point-major matrix that only this engine produces and consumes (the stored t_d): panels of BM
+  // rows, inside a panel blocks of BK columns, each block BM x BK row-major (pitch BK) - the A tile of a k-tile and the
+  // 16-column blocks of an output tile are then single contiguous 16 KB pieces instead of 128 row segments 16 KB apart.
+  // lda / ldc keep meaning "columns of the whole matrix".  FAST kernels, non-transposed A / vector epilogue only.
+  int a_blocked = 0, c_blocked = 0;
   int tri_half = 1;    // half-MFMA k-tiles on the diagonal block of a triangular B (0 = off, tuning)
   int tri_part = 0;    // TRI_OUT_LOWER with a compact grid: 0 = every active tile; 1 = only tiles that need all their
                        // rows; 2 = only tiles whose first BM/2 rows lie strictly above the diagonal (kernel ROWSEL = 1
@@ -469,14 +474,18 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     const bool blk_scale = (!TA) && SCALED && g.a_wrap == 0;       // ... or A holds all K columns: the scale follows the k-blocks
     // Addressing: one wave-uniform base pointer per operand (scalar registers, advanced per k-tile) plus constant
     // 32-bit per-lane byte offsets, so that the loads use the scalar-base form and no 64-bit vector adds.
-    const char* ua = reinterpret_cast<const char*>(TA ? A + klo * g.lda + m0 : A + m0 * g.lda + ((wrap || wrap2) ? 0 : klo));
+    const bool ablk = !TA && g.a_blocked;
+    const char* ua = reinterpret_cast<const char*>(TA ? A + klo * g.lda + m0
+                                                      : ablk ? A + m0 * g.lda + klo * BM
+                                                             : A + m0 * g.lda + ((wrap || wrap2) ? 0 : klo));
     const char* ub = reinterpret_cast<const char*>(TB ? B + n0 * g.ldb + klo : B + klo * g.ldb + n0);
     unsigned offa[Cfg::A_PASS], offb[Cfg::B_PASS], offs[Cfg::A_PASS];
 #pragma unroll
-    for (int p = 0; p < Cfg::A_PASS; ++p) offa[p] = (unsigned)(((long)(p * Cfg::A_RPP + a_tr) * g.lda + a_tc) * 8);
+    for (int p = 0; p < Cfg::A_PASS; ++p)
+      offa[p] = (unsigned)(((long)(p * Cfg::A_RPP + a_tr) * (ablk ? (long)BK : g.lda) + a_tc) * 8);
 #pragma unroll
     for (int p = 0; p < Cfg::B_PASS; ++p) offb[p] = (unsigned)(((long)(p * Cfg::B_RPP + b_tr) * g.ldb + b_tc) * 8);
-    const long a_kstride = (TA ? g.lda : 1) * 8, b_kstride = (TB ? 1 : g.ldb) * 8;   // bytes per unit of k
+    const long a_kstride = (TA ? g.lda : (ablk ? (long)BM : 1)) * 8, b_kstride = (TB ? 1 : g.ldb) * 8;   // bytes per unit of k
     // scale source: mode 1 -> ascale[(m0 + row)*as_ld + d], constant within a d-block; mode 2 -> ascale[k*as_ld + batch]
     const char* us = nullptr;
     long s_kstride = 0;
@@ -647,13 +656,16 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     if (!atomic && !g.beta && g.eadd == nullptr) {
       // interior tile, 16-byte aligned outputs (host-checked): a lane's four values of a fragment are four
       // consecutive columns -> two 16-byte stores instead of four scattered 8-byte ones
-      const long o00 = (m0 + (long)wr * 16 + 4 * (li >> 2) + lk) * g.ldc + n0 + (long)wc * 16 + 4 * (li & 3);
-      const long istep = (long)WR * 16 * g.ldc;
+      // row-major: row * ldc + col.  Blocked: panel base + 16-column block * (BM * 16) + row-in-tile * 16 + col-in-block
+      const long o00 = g.c_blocked ? m0 * g.ldc + (n0 / 16 + wc) * (long)(BM * 16) + ((long)wr * 16 + 4 * (li >> 2) + lk) * 16 + 4 * (li & 3)
+                                   : (m0 + (long)wr * 16 + 4 * (li >> 2) + lk) * g.ldc + n0 + (long)wc * 16 + 4 * (li & 3);
+      const long istep = g.c_blocked ? (long)WR * 16 * 16 : (long)WR * 16 * g.ldc;
+      const long jstep = g.c_blocked ? (long)WC * BM * 16 : (long)WC * 16;
 #pragma unroll
       for (int i = (ROWSEL == 1 ? FM / 2 : 0); i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-          const long o = o00 + i * istep + (long)j * WC * 16;
+          const long o = o00 + i * istep + j * jstep;
           d2_t v0 = {acc[i][j][0], acc[i][j][1]}, v1 = {acc[i][j][2], acc[i][j][3]};
           if (g.C2 != nullptr) {
             *reinterpret_cast<d2_t*>(g.C2 + o) = v0 * *reinterpret_cast<const d2_t*>(g.emul + o);

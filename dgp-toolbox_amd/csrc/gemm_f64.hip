@@ -119,6 +119,11 @@ static hipError_t dispatch(hipStream_t st, const GemmArgs& a) {
   const long Mf = (a.M / BM) * BM;
   if (!TA && a.K % BK != 0) fast = false;        // K is the contiguous direction of A: no K tail handling there
   const long Kf = TA ? (a.K / BK) * BK : a.K;
+  if (a.a_blocked || a.c_blocked) {   // blocked operands exist for whole-tile interior products only (dgp_ctx.h sizes them so)
+    if (!fast || Mf != a.M || TA || a.beta || a.splits > 1 || a.C2 != nullptr || (a.c_blocked && a.eadd != nullptr) ||
+        (a.a_blocked && (a.ascale_mode == 1 && a.a_wrap)))
+      return hipErrorInvalidValue;
+  }
   if (!fast || Mf == 0 || Kf == 0) return launch_generic<TA, TB>(st, a);
   hipError_t e;
   {  // interior rows x aligned K
