@@ -114,3 +114,19 @@ def test_fp64_mfma_issue_rate(ctx):
     t = ctx.dev_mfma_peak(20000)
     print("fp64 MFMA issue rate: %.1f TFLOP/s" % t)
     assert 30.0 < t < 120.0
+
+
+def test_half_row_launches_forced_at_small_sizes():
+    """The two-part launch of lower-triangular outputs (full tiles + half-row tiles on the ROWSEL instantiation) only
+    triggers by itself at production sizes; DGP_HALF_MIN_WG=1 forces it for every such product, and the gradient /
+    natural-gradient parity tests must still hold (run in a child process: the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DGP_HALF_MIN_WG="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-k",
+                        "gradient_matches_autograd_golden or natural_gradient_step_matches_golden or medium_size"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
