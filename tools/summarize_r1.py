@@ -113,3 +113,23 @@ if mfma_csv:
         "launches_over_5ms_last_first": big[-12:],
     }, open(os.path.join(out, "r1_pmc_mfma.json"), "w"), indent=1)
     print(open(os.path.join(out, "r1_pmc_mfma.json")).read())
+
+
+# ---- LDS counters of the GEMM engine (fourth PMC pass) ----
+lds_csv = glob.glob(os.path.join(src, "pmc_lds/**/*_counter_collection.csv"), recursive=True)
+if lds_csv:
+    tot = defaultdict(float)
+    with open(lds_csv[0], newline="") as f:
+        for row in csv.DictReader(f):
+            if "gemm_f64_kernel" in row["Kernel_Name"]:
+                tot[row["Counter_Name"]] += float(row["Counter_Value"])
+    act, conf, gui = tot["SQ_LDS_IDX_ACTIVE"], tot["SQ_LDS_BANK_CONFLICT"], tot["GRBM_GUI_ACTIVE"]
+    json.dump({
+        "source": "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace, bench.py --steps 2 --warmup 1, config 2, 1 GPU",
+        "kernel": "dgp::gemm_f64_kernel (all instantiations)",
+        "formulas": "bank-conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (cycles the LDS spent re-issuing conflicting lanes over the cycles it was busy); LDS busy = SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE/8 XCDs x 256 CUs) (rocprofv3's LdsUtil expression)",
+        "lds_bank_conflict_share": conf / act if act else None,
+        "lds_busy_frac": act / (gui / 8 * 256) if gui else None,
+        "raw": dict(tot),
+    }, open(os.path.join(out, "r1_pmc_lds.json"), "w"), indent=1)
+    print(open(os.path.join(out, "r1_pmc_lds.json")).read())
