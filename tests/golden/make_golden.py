@@ -129,6 +129,51 @@ def make_training_case():
     np.savez_compressed(os.path.join(HERE, "notebook_nat_adam.npz"), **out)
 
 
+def make_mf_case():
+    """Two-fidelity MF-DGP-EM (MF_DGP_EM.py): inputs, every injected normal, parameter state, the four terms of the bound
+    and its gradients from oracle/mf_dgp_em_oracle.py (parity unpinned, see its header: this fixture guards the
+    restatement against accidental change and gives the GPU test a committed target)."""
+    import torch
+    import mf_dgp_em_oracle as mo
+    rng = np.random.default_rng(77)
+    X = [rng.uniform(0, 1, (14, 2)), rng.uniform(0, 1, (9, 3))]
+    Y = [np.sin(3 * X[0].sum(1, keepdims=True)), np.sin(3 * X[1].sum(1, keepdims=True)) + 0.1]
+    X_red = [rng.uniform(0, 1, (9, 2))]
+    S = 3
+    P = mo.make_params(X, [x.copy() for x in X], [X[1].copy()])
+    state = {}
+    with torch.no_grad():
+        for name, leaf in mo.leaves(P).items():
+            if name.endswith(".Z"):
+                v = leaf.numpy().copy()
+            elif name.endswith("q_mu"):
+                v = rng.standard_normal(tuple(leaf.shape)) * 0.5
+            elif name.endswith("q_sqrt"):
+                D, M, _ = leaf.shape
+                v = np.tril(rng.standard_normal((D, M, M)) * 0.05) + 0.4 * np.eye(M)[None]
+            elif name.endswith("white_variance"):
+                v = np.array(0.05)
+            elif name == "lik_variance":
+                v = np.array(0.3)
+            elif name == "proj_variance":
+                v = np.array(0.2)
+            else:
+                v = rng.uniform(0.7, 1.3, tuple(leaf.shape))
+            leaf.copy_(torch.as_tensor(v).reshape(leaf.shape))
+            state["p." + name] = np.asarray(v, dtype=np.float64)
+    nm = mo.draw_normals(rng, X, P, S)
+    elbo, parts, grads = mo.elbo_and_grads(P, X, Y, X_red, nm, S)
+    out = {"S": np.array(S), "elbo": np.float64(elbo), "X0": X[0], "X1": X[1], "Y0": Y[0], "Y1": Y[1], "X_red0": X_red[0],
+           "zright_red0": nm["zright"][1]["red"][0], "zright_lay0": nm["zright"][1]["layers"][0],
+           "zs0_0": nm["zs"][0][0], "zs1_0": nm["zs"][1][0], "zs1_1": nm["zs"][1][1], "ws1_0": nm["ws"][1][0],
+           "wsproj0_0": nm["ws_proj"][0][0]}
+    out.update({"part." + k: np.float64(v) for k, v in parts.items()})
+    out.update(state)
+    out.update({"g." + k: v for k, v in grads.items()})
+    np.savez_compressed(os.path.join(HERE, "mf_dgp_em_two_fidelities.npz"), **out)
+    print("mf-dgp-em elbo", elbo, parts)
+
+
 def main():
     X, Y, Z = notebook_case()
     kernels = [O.RBF(1.0, [1.0] * u) for u in [1, 1, 1]]
@@ -144,6 +189,7 @@ def main():
     make_case("case_B_nonwhite", D=3, num_units=[2, 4], Dy=2, white=False, seed=103)
     make_case("case_B_white", D=3, num_units=[2, 4], Dy=2, white=True, seed=104)
     make_training_case()
+    make_mf_case()
 
 
 if __name__ == "__main__":

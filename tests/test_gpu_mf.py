@@ -306,3 +306,40 @@ def test_mf_kernel_and_white_variance_inside_a_two_layer_stack():
             got = g[off:off + ref.size].reshape(ref.shape)
             np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(ref).max()))
             off += ref.size
+
+
+def test_mf_dgp_em_against_the_committed_fixture():
+    """The product against tests/golden/mf_dgp_em_two_fidelities.npz (no oracle call at test time)."""
+    from helpers import load
+    from dgp_dace.models.MF_DGP_EM import MultiFidelityDeepGP_EM
+    g = load("mf_dgp_em_two_fidelities")
+    X, Y, X_red = [g["X0"], g["X1"]], [g["Y0"], g["Y1"]], [g["X_red0"]]
+    mf = MultiFidelityDeepGP_EM(X, Y, X_red, seed=1)
+    m = mf.model
+    m.num_samples = int(g["S"])
+    names = {}
+    for group, layers in (("layers", m.layers), ("layers_red", m.layers_red)):
+        for i, lay in enumerate(layers):
+            pairs = [(lay.feature.left(), "Z"), (lay.q_mu, "q_mu"), (lay.q_sqrt, "q_sqrt")]
+            kn = ["variance", "lengthscales"] if lay.kind == 0 else ["corr_variance", "corr_lengthscales", "prev_variance",
+                                                                      "prev_lengthscales", "lin_variance", "in_variance",
+                                                                      "in_lengthscales"]
+            pairs += [(p, "kern." + n) for p, n in zip(lay._kpars, kn)]
+            if lay._white is not None:
+                pairs.append((lay._white, "kern.white_variance"))
+            for p, n in pairs:
+                key = f"{group}.{i}.{n}"
+                p._value = np.asarray(g["p." + key], dtype=np.float64).reshape(p._value.shape).copy()
+                names[id(p)] = key
+    for p, key in ((m.likelihood.likelihood.variance, "lik_variance"), (m.likelihood_projection.likelihood.variance, "proj_variance")):
+        p._value = np.asarray(g["p." + key], dtype=np.float64).reshape(()); names[id(p)] = key
+    nm = {"zright": [None, {"red": [g["zright_red0"]], "layers": [g["zright_lay0"]]}],
+          "zs": [[g["zs0_0"]], [g["zs1_0"], g["zs1_1"]]], "ws": [[], [g["ws1_0"]]], "ws_proj": [[g["wsproj0_0"]]]}
+    val, grads = m.ELBO_and_grad((X, Y, X_red), normals=nm)
+    assert abs(val - float(g["elbo"])) <= 1e-8 * abs(float(g["elbo"]))
+    for k, got in (("L", m.L), ("L_red", m.L_red), ("KL", m.KL), ("KL_red", m.KL_red)):
+        assert abs(got - float(g["part." + k])) <= 1e-8 * max(1.0, abs(float(g["part." + k])))
+    for p in m.parameters():
+        ref = g["g." + names[id(p)]].reshape(p._value.shape)
+        np.testing.assert_allclose(np.asarray(grads[id(p)]).reshape(p._value.shape), ref, rtol=1e-6,
+                                   atol=1e-7 * max(1.0, np.abs(ref).max()), err_msg=names[id(p)])

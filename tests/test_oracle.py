@@ -169,3 +169,32 @@ def test_gpr_restatement_against_scikit_learn():
         h = 1e-6
         fd = (G.log_marginal_likelihood(ok, X, Y, noise + h) - G.log_marginal_likelihood(ok, X, Y, noise - h)) / (2 * h)
         assert abs(fd - gn) < 1e-5 * max(1.0, abs(fd))
+
+
+def _mf_from_fixture(g):
+    """Oracle parameter set, data and normals of tests/golden/mf_dgp_em_two_fidelities.npz."""
+    import torch
+    import mf_dgp_em_oracle as mo
+    X, Y, X_red = [g["X0"], g["X1"]], [g["Y0"], g["Y1"]], [g["X_red0"]]
+    P = mo.make_params(X, [x.copy() for x in X], [X[1].copy()])
+    with torch.no_grad():
+        for name, leaf in mo.leaves(P).items():
+            leaf.copy_(torch.as_tensor(g["p." + name]).reshape(leaf.shape))
+    nm = {"zright": [None, {"red": [g["zright_red0"]], "layers": [g["zright_lay0"]]}],
+          "zs": [[g["zs0_0"]], [g["zs1_0"], g["zs1_1"]]], "ws": [[], [g["ws1_0"]]], "ws_proj": [[g["wsproj0_0"]]]}
+    return P, X, Y, X_red, nm, int(g["S"])
+
+
+def test_mf_dgp_em_restatement_reproduces_its_fixture():
+    """The committed multi-fidelity vectors (inputs, injected normals, parameter state -> four terms of the bound and the
+    gradients) are reproduced by oracle/mf_dgp_em_oracle.py: a guard against accidental changes of the restatement."""
+    import mf_dgp_em_oracle as mo
+    g = load("mf_dgp_em_two_fidelities")
+    P, X, Y, X_red, nm, S = _mf_from_fixture(g)
+    elbo, parts, grads = mo.elbo_and_grads(P, X, Y, X_red, nm, S)
+    assert abs(elbo - float(g["elbo"])) <= 1e-10 * abs(float(g["elbo"]))
+    for k, v in parts.items():
+        assert abs(v - float(g["part." + k])) <= 1e-10 * max(1.0, abs(v))
+    for k, v in grads.items():
+        ref = g["g." + k]
+        np.testing.assert_allclose(v, ref.reshape(v.shape), rtol=1e-9, atol=1e-9 * max(1.0, np.abs(ref).max()))
