@@ -298,7 +298,7 @@ int dgp_propagate_full_cov(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t
                            const double* const* zs, double* const* Fs, double* const* Fmeans, double* const* Fvars) {
   RET(check_ready(ctx, false));
   if (!Xnew || Nn <= 0 || S <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_propagate_full_cov: bad arguments");
-  if (Nn > 1024) return fail(ctx, DGP_ERR_INVALID, "dgp_propagate_full_cov: at most 1024 points (N x N covariances per sample)");
+  if (Nn > 4096) return fail(ctx, DGP_ERR_INVALID, "dgp_propagate_full_cov: at most 4096 points (N x N covariances per sample)");
   HIPCHK(hipSetDevice(ctx->device));
   const int nl = (int)ctx->L.size();
   const long N = Nn, Pm = pad_rows(N);

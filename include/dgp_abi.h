@@ -103,7 +103,7 @@ int dgp_propagate(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint6
 
 /* the full_cov=True branches of the same calls (layers.py:77-80,265-268; utils.py:43-51): per sample s and output d
  * the N x N covariance over the Nn points, samples drawn through its Cholesky factor (jitter 1e-6 as the reference).
- * Fvars entries are [S,Nn,Nn,D_out_l]; Fs / Fmeans as in dgp_propagate.  Small-N path: Nn <= 1024.             */
+ * Fvars entries are [S,Nn,Nn,D_out_l]; Fs / Fmeans as in dgp_propagate.  Small-N path: Nn <= 4096.             */
 int dgp_propagate_full_cov(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t S, uint64_t seed,
                            const double* const* zs, double* const* Fs, double* const* Fmeans, double* const* Fvars);
 

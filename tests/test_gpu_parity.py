@@ -996,3 +996,24 @@ def test_numerical_failures_surface_as_exceptions():
         m.ELBO((X, Ybad))
     assert np.isfinite(m.ELBO((X, Y)))
     del e0
+
+
+def test_full_cov_beyond_1024_points():
+    """full_cov=True past N = 1024 (N = 1200 prediction points, padded to 1216): first-layer covariance and samples
+    against the NumPy restatement, and its diagonal against the diagonal path."""
+    g = load(CASES[0])
+    m = product_from_golden(g)
+    om = oracle_from_golden(g)
+    nl = n_layers(g)
+    rng = np.random.default_rng(12)
+    N, S = 1200, 1
+    Xn = rng.uniform(-1, 1, (N, g["X"].shape[1]))
+    zn = [rng.standard_normal((S, N, l.num_outputs)) for l in m.layers]
+    Fs, Fm, Fv = m.propagate(Xn, full_cov=True, S=S, zs=zn)
+    oFs, oFm, oFv = om.propagate(Xn, S, zn, full_cov=True)
+    for i in range(nl):        # (the samples pass through the Cholesky factor of a 1200 x 1200 covariance with 1e-6 jitter:
+        _close(Fm[i], oFm[i], rtol=1e-6, atol=1e-8)          #  rounding differences of 1e-16 reach 1e-9 in the next layer's inputs)
+        _close(Fv[i], oFv[i], rtol=1e-6, atol=1e-8)
+        _close(Fs[i], oFs[i], rtol=1e-5, atol=1e-6)
+    _, _, Fv_d = m.propagate(Xn, S=S, zs=zn)
+    _close(np.einsum("siid->sid", np.asarray(Fv[0])), Fv_d[0], rtol=1e-8, atol=1e-10)
