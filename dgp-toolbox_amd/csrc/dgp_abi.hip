@@ -146,7 +146,7 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
   for (auto& y : ctx->L) {
     const long MM = (long)y.Mp * y.Mp;
     const int D = y.d.D_out;
-    RET(dev_alloc(ctx, &y.Kuu, MM)); RET(dev_alloc(ctx, &y.Lu, MM)); RET(dev_alloc(ctx, &y.Linv, MM));
+    RET(dev_alloc(ctx, &y.Kuu, MM)); RET(dev_alloc(ctx, &y.Lu, MM)); RET(dev_alloc(ctx, &y.Linv, MM)); RET(dev_alloc(ctx, &y.LinvT, MM));
     RET(dev_alloc(ctx, &y.Lq, MM * D)); RET(dev_alloc(ctx, &y.qmu_p, (long)y.Mp * D));
     RET(dev_alloc(ctx, &y.Wcat, MM * D)); RET(dev_alloc(ctx, &y.u, (long)y.Mp * D)); RET(dev_alloc(ctx, &y.Scat, MM * D)); RET(dev_alloc(ctx, &y.Z1, (long)y.Mp * (y.d.D_in + 1)));
     if (y.d.kernel_kind == DGP_KERNEL_MATERN32 || y.d.kernel_kind == DGP_KERNEL_MATERN52) { RET(dev_alloc(ctx, &y.Euu, MM)); RET(dev_alloc(ctx, &y.kdot, 1)); }

@@ -39,6 +39,7 @@ struct Layer {
   long off_white = -1;                               // white.variance when the kernel carries a White term
   double *meanW = nullptr, *meanb = nullptr;
   double *Kuu, *Lu, *Linv, *Lq, *qmu_p, *Wcat, *u;   // derived small matrices (padded to Mp)
+  double *LinvT = nullptr;                           // Linv^T: the B operand of c = Lu^-1 k as an NN product (wide-tile kernel)
   double *Scat;                                      // [D*Mp x Mp] (backward only): W_d^T stacked when t_d is kept from the
                                                      // forward pass (ctx->store_t), else S'_d = W_d W_d^T - I stacked
   double *Tt = nullptr;                              // [points][D*Mp]: t_d = W_d^T c (training chunks, ctx->store_t)
@@ -331,7 +332,7 @@ int grow(dgp_ctx* ctx, double** p, size_t* cap, size_t n) {
 void free_model(dgp_ctx* ctx) {
   ctx->prep_level = 0;
   for (auto& l : ctx->L) {
-    dev_free(l.Kuu); dev_free(l.Lu); dev_free(l.Linv); dev_free(l.Lq); dev_free(l.qmu_p); dev_free(l.Wcat);
+    dev_free(l.Kuu); dev_free(l.Lu); dev_free(l.Linv); dev_free(l.LinvT); dev_free(l.Lq); dev_free(l.qmu_p); dev_free(l.Wcat);
     dev_free(l.u); dev_free(l.Scat); dev_free(l.Z1); dev_free(l.Euu); dev_free(l.kdot); dev_free(l.dLq); dev_free(l.dqmu_p);
   }
   ctx->L.clear();
@@ -454,6 +455,7 @@ int prep(dgp_ctx* ctx, bool train = false) {
     if (y.off_white >= 0) HIPCHK(add_diag_dev(ctx->st, y.Kuu, M, Mp, P(ctx, y.off_white)));
     HIPCHK(copy_mat(ctx->st, y.Kuu, y.Lu, MM));
     HIPCHK(potrf_inv(ctx->st, y.Lu, y.Linv, ctx->sm[9], Mp, 1, ctx->info));
+    HIPCHK(wcat_transpose(ctx->st, y.Linv, Mp, 1, y.LinvT));
     if (y.d.white) {
       HIPCHK(lq_to_wcat(ctx->st, y.Lq, Mp, D, y.Wcat));
       HIPCHK(copy_mat(ctx->st, y.qmu_p, y.u, (long)Mp * D));
@@ -498,7 +500,17 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
     const long Pl = dedup ? Nc : (long)S * Nc, Pm = pad_rows(Pl);
     const double* Xin = dedup ? Xsrc : ctx->L[l - 1].F;
     const long row0 = dedup ? n0 : 0;
-    const int nplane = Mp / 32;
+    const double tri1 = (double)Pl * Mp * (Mp + 1.0);   // 2 * M(M+1)/2 flops per point
+    // c = Lu^-1 k (|c|^2 partials) and t_d = W_d^T c (|t_d|^2 partials always leave the kernel; t_d itself only for
+    // the backward pass, store_t).  Both run on the wide-tile kernel (gemm_wide.h: 2 partial planes per 256 columns)
+    // when it applies, else on the 128 x 64 engine (Mp/32 planes, the triangular solve as an NT product).
+    GemmArgs aC = mk(Pm, Mp, Mp, y.Kt, Mp, y.LinvT, Mp, y.Ct, Mp);
+    aC.tri = TRI_B_UPPER; aC.triblk = Mp; aC.epi = 2; aC.rowsq = y.cnp; aC.rowsq_ld = Pm;
+    GemmArgs aT = mk(Pm, (long)D * Mp, Mp, y.Ct, Mp, y.Wcat, (long)D * Mp, y.Tt, (long)D * Mp);
+    aT.tri = TRI_B_LOWER; aT.triblk = Mp; aT.epi = y.Tt ? 2 : 1; aT.rowsq = y.tnp; aT.rowsq_ld = Pm;
+    aT.c_blocked = (y.Tt && ctx->blocked_t) ? 1 : 0;       // t_d is read back only by the dC product below: blocked layout
+    const bool wide = gemm_wide_ok(aC) && gemm_wide_ok(aT);
+    const int nplane = wide ? Mp / 128 : Mp / 32;
     {
       ProfScope ps(ctx, 1, 0, (double)Pl * (Mp + Din) * 8);
       if (y.d.kernel_kind == DGP_KERNEL_MF)
@@ -507,18 +519,13 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
         HIPCHK(rbf_kuf(ctx->st, y.d.kernel_kind, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
                        y.Kt, y.Et));
     }
-    const double tri1 = (double)Pl * Mp * (Mp + 1.0);   // 2 * M(M+1)/2 flops per point
-    {  // c = Lu^-1 k  and |c|^2 partials
-      GemmArgs a = mk(Pm, Mp, Mp, y.Kt, Mp, y.Linv, Mp, y.Ct, Mp);
-      a.tri = TRI_B_UPPER; a.triblk = Mp; a.epi = 2; a.rowsq = y.cnp; a.rowsq_ld = Pm;
-      RET(GX(ctx, 0, GEMM_NT, a, tri1, (double)Pl * Mp * 16));
+    if (wide) {
+      RET(GX(ctx, 0, GEMM_NN, aC, tri1, (double)Pl * Mp * 16));
+    } else {
+      aC.B = y.Linv; aC.no_wide = 1; aT.no_wide = 1;
+      RET(GX(ctx, 0, GEMM_NT, aC, tri1, (double)Pl * Mp * 16));
     }
-    {  // t_d = W_d^T c: |t_d|^2 partials always leave the kernel; t_d itself only for the backward pass (store_t)
-      GemmArgs a = mk(Pm, (long)D * Mp, Mp, y.Ct, Mp, y.Wcat, (long)D * Mp, y.Tt, (long)D * Mp);
-      a.tri = TRI_B_LOWER; a.triblk = Mp; a.epi = y.Tt ? 2 : 1; a.rowsq = y.tnp; a.rowsq_ld = Pm;
-      a.c_blocked = (y.Tt && ctx->blocked_t) ? 1 : 0;      // t_d is read back only by the dC product below: blocked layout
-      RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 8 * (y.Tt ? 1 + D : 1)));
-    }
+    RET(GX(ctx, 0, GEMM_NN, aT, tri1 * D, (double)Pl * Mp * 8 * (y.Tt ? 1 + D : 1)));
     RET(GX(ctx, 0, GEMM_NN, mk(Pm, D, Mp, y.Ct, Mp, y.u, D, y.mean0, D), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
     {
       ProfScope ps(ctx, 1, 0, (double)Pl * nplane * 8 * (1 + D));

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "gemm_f64.h"
+#include "gemm_wide.h"
 
 namespace dgp {
 

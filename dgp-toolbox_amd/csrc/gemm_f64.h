@@ -100,6 +100,7 @@ struct GemmArgs {
   // optional second output C2 = (alpha * A B) .* E  (same shape / leading dimension as C; used for g = dK .* K)
   const double* emul = nullptr;
   double* C2 = nullptr;
+  int no_wide = 0;     // 1: keep this product on the 128 x 64 engine even where the wide-tile kernel (gemm_wide.h) applies
 };
 
 template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int VB>

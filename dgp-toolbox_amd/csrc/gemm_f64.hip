@@ -1,5 +1,6 @@
 // Host-side dispatch of the fp64 MFMA GEMM engine (see gemm_f64.h).
 #include "gemm_f64.h"
+#include "gemm_wide.h"
 #include <cstdlib>
 #include <algorithm>
 
@@ -163,6 +164,8 @@ hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args) {
   GemmArgs a = args;
   if (a.splits < 1) a.splits = 1;
   if (a.batch < 1) a.batch = 1;
+  // row-panel products with a (block-)triangular or dense Mp-wide B: the wide-tile kernel
+  if (op == GEMM_NN && !a.no_wide && gemm_wide_ok(a)) return gemm_wide(st, a);
   switch (op) {
     case GEMM_NN: return dispatch<false, false>(st, a);
     case GEMM_NT: return dispatch<false, true>(st, a);
