@@ -174,13 +174,17 @@ def main():
         mf = prof["mfma_contractions"]
         achieved = mf["alg_flops"] / (mf["ms"] * 1e-3) / 1e12 if mf["ms"] > 0 else 0.0
         name, cus, mem = ctx.device_info()
-        traffic = None          # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
-        tpath = os.environ.get("DGP_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        # HBM bytes per launch of the dominant kernel family: NOT measured in this run (PMC counters need rocprofv3 passes
+        # of their own); taken from the committed summary of those passes, whose commit / command travel with the number
+        traffic, traffic_source = None, None
+        tpath = os.environ.get("DGP_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
         if world == 1 and os.path.exists(tpath) and (args.N, args.M, args.S) == (100_000, 256, 10):
             try:
-                traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+                tj = json.load(open(tpath))
+                traffic = tj["hbm_bytes_per_launch"]
+                traffic_source = f"{os.path.relpath(tpath, ROOT)} (rocprofv3 PMC passes at commit {tj.get('commit', '?')}: {tj.get('source', '')})"
             except Exception:
-                traffic = None
+                traffic, traffic_source = None, None
         out = {
             "metric": "ELBO iterations/sec (2-layer DGP, N=100k, M=256) at 1/2/4/8 GPUs; fp64 ELBO match",
             "value": it_s, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -189,10 +193,10 @@ def main():
             "config": {"workload": f"DGP num_units={num_units} ({len(num_units) + 1} SVGP layers), N={args.N}, "
                                    f"D={args.D}, M={args.M}, S={args.S}, " + (f"minibatch {args.minibatch}" if args.minibatch else "full batch") + ", optimize_adam iteration",
                        "N": args.N, "D": args.D, "M": args.M, "S": args.S, "num_units": num_units,
-                       "parallelism": f"data points sharded over {world} GPU(s), one all-reduce per iteration"},
+                       "parallelism": f"data points sharded over {world} GPU(s), one all-reduce per layer and iteration, overlapped with the backward pass"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "dgp::gemm_f64_kernel (all point contractions, rank 0)",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "dgp::gemm_wide_kernel + dgp::gemm_f64_kernel (all point contractions, rank 0)",
                          "kernel_ms_per_step": mf["ms"] / args.steps, "launches_per_step": mf["launches"] / args.steps,
                          "alg_flops_per_step_rank0": mf["alg_flops"] / args.steps,
                          "whole_step_frac": alg_flops_step(args.minibatch or args.N, args.S, dims, args.M, 1) / world / (dt / args.steps)
@@ -214,31 +218,59 @@ def main():
         dist.destroy_process_group()
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(args, num_units, X, Y, Z):
-    """Oracle (torch-CPU fp64 restatement of the reference's dense formulation, autograd backward) timed on
-    the first `cpu_sample` data points, all host cores; rate extrapolated linearly in N.  Also checks the
-    GPU ELBO against the oracle on that sample with identical Philox normals."""
+    """the oracle's torch-CPU fp64 restatement of the reference's dense formulation
+    (layers.py:243-276, autograd backward, Keras-Adam update: one `optimize_adam` loop body, dgp.py:271-276) on all
+    host cores.  Protocol: per sample size 1 warm-up + 3 timed iterations, median; the sample is evaluated as ONE
+    block of points (no small chunks that would handicap BLAS); two sample sizes (n/2 and n) to show that the time is
+    linear in the number of points before it is extrapolated to N.  Also checks the GPU ELBO against the oracle on the
+    larger sample with identical Philox normals."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch
     import dgp_oracle as O
-    import dgp_oracle_torch as T
+    from dgp_oracle_train import OracleTrainer
     from dgp_dace.gpflow_compat import RBF, Gaussian
     from dgp_dace.models.dgp import DGP
     cores = usable_cores()
-    log(f"cpu_baseline: {cores} cores")
+    cpu = cpu_model_name()
+    log(f"cpu_baseline: {cores} cores, {cpu}")
     torch.set_num_threads(cores)
-    n = min(args.cpu_sample, args.N)
+    n_big = min(args.cpu_sample, args.N)
     dims = [args.D] + num_units
-    Xs, Ys = X[:n].copy(), Y[:n].copy()
+    med = {}
+    for n in sorted({max(256, n_big // 2), n_big}):
+        Xs, Ys = X[:n].copy(), Y[:n].copy()
+        mo = O.OracleDGP(Xs, Ys, Z, [O.RBF(1.0, np.ones(d)) for d in dims], num_units, num_samples=args.S)
+        tr = OracleTrainer(mo, base_seed=0)
+        tr.scale_inner_q_sqrt()
+        adam = tr.new_adam(0.01, 0.9, 0.999, 1e-7)
+        times = []
+        for it in range(4):                       # the first one is the warm-up
+            t0 = time.perf_counter()
+            tr.adam_iteration(adam)
+            times.append(time.perf_counter() - t0)
+        med[n] = float(np.median(times[1:]))
+        log(f"cpu_baseline: n={n}: iterations {['%.2f' % t for t in times]} s, median of the last three {med[n]:.2f} s")
+    ns = sorted(med)
+    lin = (med[ns[-1]] / med[ns[0]]) / (ns[-1] / ns[0]) if len(ns) > 1 else 1.0
+    t = med[n_big]
+    # ELBO of the GPU path against the oracle on the larger sample, same Philox normals
+    Xs, Ys = X[:n_big].copy(), Y[:n_big].copy()
     mo = O.OracleDGP(Xs, Ys, Z, [O.RBF(1.0, np.ones(d)) for d in dims], num_units, num_samples=args.S)
     for l in mo.layers[:-1]:
         l.q_sqrt = l.q_sqrt * 1e-3
-    zs = O.draw_zs(mo, 123, args.S, n)
-    T.elbo_and_grads(mo, [z[:, :256] for z in zs], data=(Xs[:256], Ys[:256]), chunk=256)   # warm-up
-    t0 = time.perf_counter()
-    elbo_o, _ = T.elbo_and_grads(mo, zs, chunk=256)
-    t = time.perf_counter() - t0
-    log(f"cpu_baseline: timed evaluation {t:.2f} s")
+    import dgp_oracle_torch as T
+    elbo_o, _ = T.elbo_and_grads(mo, O.draw_zs(mo, 123, args.S, n_big), want_grads=False)
     stdout = sys.stdout
     sys.stdout = open(os.devnull, "w")
     mg = DGP(Xs, Ys, Z, [RBF(1.0, [1.0] * d) for d in dims], num_units, Gaussian(), num_samples=args.S)
@@ -249,9 +281,12 @@ def cpu_baseline(args, num_units, X, Y, Z):
     mg._sync_data(mg.data)
     Ld, KL = c.elbo(args.S, 123, None)
     rel = abs((Ld - KL) - elbo_o) / abs(elbo_o)
-    return {"value": 1.0 / (t * args.N / n), "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of {args.N} data points (S={args.S}), 1 timed ELBO+autograd evaluation = {t:.2f} s, "
-                      f"extrapolated linearly in N; torch-CPU fp64, dense SK@A formulation of layers.py:243-276",
+    return {"value": 1.0 / (t * args.N / n_big), "unit": "it/s", "cores": cores, "kind": "port", "cpu": cpu,
+            "sample": f"{n_big} of {args.N} data points (S={args.S}) as one block: 1 warm-up + 3 timed optimize_adam iterations "
+                      f"(ELBO + autograd + Adam), median {t:.2f} s; {ns[0]} points: median {med[ns[0]]:.2f} s, i.e. time per point "
+                      f"x{lin:.2f} from {ns[0]} to {ns[-1]} points (1.00 = linear), extrapolated linearly in N; torch-CPU fp64, "
+                      f"dense SK@A formulation of layers.py:243-276",
+            "seconds_per_iteration": {str(k): v for k, v in med.items()}, "linearity": lin,
             "elbo_rel_err": rel}
 
 

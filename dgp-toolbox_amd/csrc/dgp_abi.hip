@@ -1,5 +1,8 @@
 // libdgp_hip.so: the C-ABI of the SVGP-layer ELBO path (include/dgp_abi.h) on top of dgp_ctx.h.
 #include "dgp_ctx.h"
+#include <dlfcn.h>
+
+struct ncclUniqueIdBytes { char internal[128]; };   // rccl.h: ncclUniqueId (passed by value to ncclCommInitRank)
 
 // =================================================================================== C-ABI
 extern "C" {
@@ -40,6 +43,11 @@ int dgp_create(int device, void* hip_stream, dgp_ctx** out) {
       ok = hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) == hipSuccess &&
            hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) ctx->use_side = false;
+    for (int i = 0; i < dgp_ctx::kMaxEv && ok; ++i)
+      ok = hipEventCreateWithFlags(&ctx->ev_prep[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&ctx->ev_layer[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { ctx->ev_prep[0] = nullptr; (void)hipGetLastError(); }
   }
   *out = ctx;
   return DGP_OK;
@@ -58,6 +66,12 @@ void dgp_destroy(dgp_ctx* ctx) {
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  (void)dgp_comm_destroy(ctx);
+  for (int i = 0; i < dgp_ctx::kMaxEv; ++i) {
+    if (ctx->ev_prep[i]) (void)hipEventDestroy(ctx->ev_prep[i]);
+    if (ctx->ev_layer[i]) (void)hipEventDestroy(ctx->ev_layer[i]);
+    if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->st);
   delete ctx;
 }
@@ -480,16 +494,13 @@ int dgp_acc_bind(dgp_ctx* ctx, void* external_device_ptr) {
   return DGP_OK;
 }
 
-int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out) {
-  RET(check_ready(ctx, false));
-  HIPCHK(hipSetDevice(ctx->device));
+// Small-matrix chain of ONE layer after its point sums are final (and summed over the ranks): Cholesky backward, KL
+// gradient, kernel-hyper-parameter gradients -> that layer's entries of d ELBO / d params.  Launches on ctx->st with the
+// scratch set ctx->sm (the caller selects a side stream + its scratch for concurrent layers).
+static int finish_layer(dgp_ctx* ctx, size_t li) {
   double* acc = ctx->acc;
   double* g = ctx->grad;
-  {
-  LayerFork fork(ctx, (int)ctx->L.size());
-  for (size_t li = 0; li < ctx->L.size(); ++li) {
     Layer& y = ctx->L[li];
-    fork.use((int)li);
     const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
     const long MM = (long)Mp * Mp, DM = (long)D * Mp;
     double *T1 = ctx->sm[0], *T2 = ctx->sm[1], *T3 = ctx->sm[2], *T4 = ctx->sm[3], *Sm = ctx->sm[4];
@@ -535,11 +546,188 @@ int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out) {
     }
     if (y.off_white >= 0) HIPCHK(white_grad(ctx->st, Sm, M, Mp, acc + y.acc_dvar, g + y.off_white));
     HIPCHK(unpack_q_grads(ctx->st, y.dLq, y.dqmu_p, M, Mp, D, g + y.off_qsqrt, g + y.off_qmu));
-  }
-  }
-  HIPCHK(copy_mat(ctx->st, acc + 1, g + ctx->n_params - 1, 1));
-  HIPCHK(sub_scalars(ctx->st, acc + 0, ctx->scal + 0, ctx->scal + 1));   // ELBO = data term - sum KL
+  return DGP_OK;
+}
+
+static int finish_tail(dgp_ctx* ctx) {
+  HIPCHK(copy_mat(ctx->st, ctx->acc + 1, ctx->grad + ctx->n_params - 1, 1));
+  HIPCHK(sub_scalars(ctx->st, ctx->acc + 0, ctx->scal + 0, ctx->scal + 1));   // ELBO = data term - sum KL
   ctx->grad_ready = true;
+  return DGP_OK;
+}
+
+int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out) {
+  RET(check_ready(ctx, false));
+  HIPCHK(hipSetDevice(ctx->device));
+  {
+    LayerFork fork(ctx, (int)ctx->L.size());
+    for (size_t li = 0; li < ctx->L.size(); ++li) {
+      fork.use((int)li);
+      RET(finish_layer(ctx, li));
+    }
+  }
+  RET(finish_tail(ctx));
+  if (elbo_out) return dgp_last_elbo(ctx, elbo_out);
+  return DGP_OK;
+}
+
+// ------------------------------------------------------------------------------- RCCL (loaded at run time)
+namespace {
+struct NcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, ncclUniqueIdBytes, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+NcclApi g_nccl;
+constexpr int kNcclFloat64 = 8, kNcclSum = 0;     // ncclDataType_t / ncclRedOp_t values of rccl.h
+
+int nccl_load(dgp_ctx* ctx) {
+  if (g_nccl.lib) return DGP_OK;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);        // the process's copy when one is loaded already
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(ctx, DGP_ERR_INVALID, "dgp_comm: librccl.so not found");
+  NcclApi a;
+  a.lib = h;
+  a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+  a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+  a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.GroupStart || !a.GroupEnd || !a.CommDestroy)
+    return fail(ctx, DGP_ERR_INVALID, "dgp_comm: librccl.so lacks an expected symbol");
+  g_nccl = a;
+  return DGP_OK;
+}
+int nccl_chk(dgp_ctx* ctx, int rc, const char* what) {
+  if (rc == 0) return DGP_OK;
+  char buf[256];
+  snprintf(buf, sizeof buf, "%s: %s", what, g_nccl.GetErrorString ? g_nccl.GetErrorString(rc) : "RCCL error");
+  return fail(ctx, DGP_ERR_HIP, buf);
+}
+}  // namespace
+
+int dgp_comm_unique_id(void* id128_out) {
+  if (!id128_out) return DGP_ERR_INVALID;
+  RET(nccl_load(nullptr));
+  return g_nccl.GetUniqueId(id128_out) == 0 ? DGP_OK : DGP_ERR_HIP;
+}
+
+int dgp_comm_init(dgp_ctx* ctx, int32_t rank, int32_t world, const void* id128) {
+  if (!ctx || world < 1 || rank < 0 || rank >= world) return fail(ctx, DGP_ERR_INVALID, "dgp_comm_init: bad rank / world");
+  RET(dgp_comm_destroy(ctx));
+  ctx->comm_rank = rank;
+  ctx->comm_world = world;
+  if (world == 1) return DGP_OK;
+  if (!id128) return fail(ctx, DGP_ERR_INVALID, "dgp_comm_init: no unique id");
+  RET(nccl_load(ctx));
+  HIPCHK(hipSetDevice(ctx->device));
+  ncclUniqueIdBytes id;
+  memcpy(&id, id128, sizeof id);
+  void* comm = nullptr;
+  RET(nccl_chk(ctx, g_nccl.CommInitRank(&comm, world, id, rank), "ncclCommInitRank"));
+  ctx->nccl_comm = comm;
+  return DGP_OK;
+}
+
+int dgp_comm_destroy(dgp_ctx* ctx) {
+  if (!ctx) return DGP_ERR_INVALID;
+  if (ctx->nccl_comm && g_nccl.CommDestroy) {
+    (void)hipStreamSynchronize(ctx->st);
+    (void)g_nccl.CommDestroy(ctx->nccl_comm);
+  }
+  ctx->nccl_comm = nullptr;
+  ctx->comm_world = 1;
+  ctx->comm_rank = 0;
+  return DGP_OK;
+}
+
+int dgp_comm_allreduce(dgp_ctx* ctx, void* device_ptr, int64_t n_doubles) {
+  if (!ctx || !device_ptr || n_doubles < 0) return fail(ctx, DGP_ERR_INVALID, "dgp_comm_allreduce: bad argument");
+  if (ctx->comm_world <= 1 || n_doubles == 0) return DGP_OK;
+  if (!ctx->nccl_comm) return fail(ctx, DGP_ERR_INVALID, "dgp_comm_allreduce: call dgp_comm_init first");
+  return nccl_chk(ctx, g_nccl.AllReduce(device_ptr, device_ptr, (size_t)n_doubles, kNcclFloat64, kNcclSum, ctx->nccl_comm, ctx->st),
+                  "ncclAllReduce");
+}
+
+// ------------------------------------------------------------------------------- overlapped gradient evaluation
+namespace {
+// backward_chunk hook (last chunk only): layer l's sums are final -> on a side stream: all-reduce its slice, then its chain
+int after_layer_hook(dgp_ctx* ctx, int l) {
+  const int nl = (int)ctx->L.size();
+  Layer& y = ctx->L[l];
+  const long lo = y.acc_Q, hi = (l + 1 < nl) ? ctx->L[l + 1].acc_Q : ctx->n_acc;     // the layer's contiguous slice
+  const bool comm = ctx->comm_world > 1 && ctx->nccl_comm != nullptr;
+  const bool side = ctx->use_side && nl <= dgp_ctx::kMaxEv && ctx->ev_layer[0] != nullptr;
+  hipStream_t main_st = ctx->st;
+  hipStream_t st = main_st;
+  int w = 0;
+  if (side) {
+    w = 1 + ((nl - 1 - l) % 2);                 // alternate the two side streams, top layer first
+    st = ctx->side[w - 1];
+    HIPCHK(hipEventRecord(ctx->ev_layer[l], main_st));
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_layer[l], 0));
+  }
+  if (comm) {
+    RET(nccl_chk(ctx, g_nccl.GroupStart(), "ncclGroupStart"));
+    int rc = 0;
+    if (l == nl - 1)      // the two scalars at the head of the buffer (ELBO data term, likelihood-variance gradient)
+      rc = g_nccl.AllReduce(ctx->acc, ctx->acc, 2, kNcclFloat64, kNcclSum, ctx->nccl_comm, st);
+    if (rc == 0) rc = g_nccl.AllReduce(ctx->acc + lo, ctx->acc + lo, (size_t)(hi - lo), kNcclFloat64, kNcclSum, ctx->nccl_comm, st);
+    const int rc2 = g_nccl.GroupEnd();
+    RET(nccl_chk(ctx, rc ? rc : rc2, "ncclAllReduce"));
+  }
+  ctx->st = st;
+  ctx->sm = ctx->smset[w];
+  const int r = finish_layer(ctx, (size_t)l);
+  ctx->st = main_st;
+  ctx->sm = ctx->smset[0];
+  RET(r);
+  if (side) HIPCHK(hipEventRecord(ctx->ev_done[l], st));
+  return DGP_OK;
+}
+}  // namespace
+
+int dgp_grad_step(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs, double* elbo_out) {
+  RET(check_ready(ctx, true));
+  if (S <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_grad_step: S must be positive");
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->grad_ready = false;
+  if (zs) RET(upload_zs(ctx, zs, S, ctx->N));
+  RET(prep(ctx, true, true));
+  HIPCHK(hipMemsetAsync(ctx->acc, 0, ctx->n_acc * 8, ctx->st));
+  long Nc = 0;
+  const long lo = ctx->batch_n ? ctx->batch_lo : 0, hi = ctx->batch_n ? ctx->batch_lo + ctx->batch_n : ctx->N;
+  RET(ensure_ws(ctx, hi - lo, S, true, &Nc));
+  Layer& last = ctx->L.back();
+  const bool dedup_last = ctx->L.size() == 1;
+  const int nl = (int)ctx->L.size();
+  bool hooked = false;
+  for (long n0 = lo; n0 < hi; n0 += Nc) {
+    const long nc = std::min(Nc, hi - n0);
+    RET(forward_chunk(ctx, ctx->X, ctx->N, n0, nc, S, seed, zs != nullptr, ctx->n_goff));
+    {
+      ProfScope ps(ctx, 1, 0, 0);
+      HIPCHK(gauss_lik(ctx->st, last.mean, last.var, ctx->Y, n0, nc, S, dedup_last ? 1 : 0, ctx->Dy,
+                       P(ctx, ctx->n_params - 1), ctx->acc + 0, ctx->acc + 1, last.mbar, last.vbar,
+                       ctx->acc + last.acc_dvar, ctx->data_scale));
+    }
+    BwdOpts o{ctx->X, ctx->N, ctx->n_goff, true, false};
+    if (n0 + nc >= hi) { o.after_layer = after_layer_hook; hooked = true; }     // sums are final in the last chunk only
+    RET(backward_chunk(ctx, n0, nc, S, seed, zs != nullptr, o));
+  }
+  if (!hooked) {          // no data points on this rank: the chains still have to run (KL part), after the all-reduces
+    for (int l = nl - 1; l >= 0; --l) RET(after_layer_hook(ctx, l));
+  }
+  if (ctx->use_side && nl <= dgp_ctx::kMaxEv && ctx->ev_layer[0] != nullptr)
+    for (int l = 0; l < nl; ++l) HIPCHK(hipStreamWaitEvent(ctx->st, ctx->ev_done[l], 0));
+  RET(finish_tail(ctx));
   if (elbo_out) return dgp_last_elbo(ctx, elbo_out);
   return DGP_OK;
 }

@@ -121,6 +121,14 @@ struct dgp_ctx {
                            // the multi-fidelity graph) factorise Kuu once.
   bool segs_uploaded = false;
   Prof prof;
+  // overlap machinery of dgp_grad_step: per-layer events (prep done / backward left the layer / finish chain done)
+  static constexpr int kMaxEv = 16;
+  hipEvent_t ev_prep[kMaxEv] = {nullptr}, ev_layer[kMaxEv] = {nullptr}, ev_done[kMaxEv] = {nullptr};
+  bool prep_wait[kMaxEv] = {false};
+  // library-owned RCCL communicator (dgp_comm_init); the functions come from dlopen("librccl.so.1")
+  void* nccl_lib = nullptr;
+  void* nccl_comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
 };
 
 namespace {
@@ -129,7 +137,10 @@ int fail(dgp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
   char buf[512];
   if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
   else snprintf(buf, sizeof buf, "%s", what);
-  if (ctx) ctx->err = buf;
+  if (ctx) {
+    ctx->err = buf;
+    if (code != DGP_ERR_INVALID) ctx->prep_level = 0;   // device-side failure: the cached factorisation may be partial
+  }
   return code;
 }
 
@@ -401,17 +412,36 @@ size_t carve(dgp_ctx* ctx, char* base, long Nc, int S, bool train) {
 }
 
 int ensure_ws(dgp_ctx* ctx, long N, int S, bool train, long* Nc_out) {
+  // the chunk of data points is sized from min(user limit, ~80 % of what the device has free right now + what the
+  // context already holds): two ranks on one GPU, a co-tenant or a smaller part then run in more chunks instead of
+  // failing; a refused allocation is retried with a smaller chunk
+  size_t limit = (size_t)ctx->ws_limit;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const size_t avail = (size_t)((free_b + ctx->ws_cap) * 0.8);
+      if (avail < limit) limit = avail;
+    } else {
+      (void)hipGetLastError();
+    }
+    if (limit < (64u << 20)) limit = 64u << 20;
+  }
   const size_t per1 = carve(ctx, nullptr, 1024, S, train) / 1024 + 1;
-  long Nc = (long)((size_t)ctx->ws_limit / per1);
+  long Nc = (long)(limit / per1);
   if (Nc < 1) Nc = 1;
   if (Nc > N) Nc = N;
   size_t need = carve(ctx, nullptr, Nc, S, train);
-  while (need > (size_t)ctx->ws_limit && Nc > 1) { Nc = Nc * 9 / 10; need = carve(ctx, nullptr, Nc, S, train); }
-  if (need > ctx->ws_cap) {
+  while (need > limit && Nc > 1) { Nc = Nc * 9 / 10; need = carve(ctx, nullptr, Nc, S, train); }
+  while (need > ctx->ws_cap) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     ctx->ws = nullptr; ctx->ws_cap = 0;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&ctx->ws), need));
-    ctx->ws_cap = need;
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->ws), need);
+    if (e == hipSuccess) { ctx->ws_cap = need; break; }
+    (void)hipGetLastError();
+    ctx->ws = nullptr;
+    if (Nc <= 1) return fail(ctx, DGP_ERR_HIP, "workspace allocation", e);
+    Nc = Nc > 16 ? Nc / 2 : 1;
+    need = carve(ctx, nullptr, Nc, S, train);
   }
   carve(ctx, ctx->ws, Nc, S, train);
   *Nc_out = Nc;
@@ -433,17 +463,37 @@ int upload_zs(dgp_ctx* ctx, const double* const* zs, int S, long Ntot) {
 inline const double* P(dgp_ctx* ctx, long off) { return ctx->params + off; }
 
 // ------------------------------------------------------------------------------- prep: small matrices + KL
-int prep(dgp_ctx* ctx, bool train = false) {
+// `overlap`: the chains of the layers above the first run on the side streams WITHOUT a join; forward_chunk waits for
+// layer l's event right before it needs that layer's matrices (the first layer's forward pass covers the others' chains)
+int prep(dgp_ctx* ctx, bool train = false, bool overlap = false) {
   if (ctx->prep_level >= (train ? 2 : 1)) {        // parameters unchanged: keep the factorisation and the KL in scal[0]
     HIPCHK(hipMemsetAsync(ctx->scal + 1, 0, 3 * sizeof(double), ctx->st));
     return DGP_OK;
   }
-  ctx->prep_level = train ? 2 : 1;
+  ctx->prep_level = 0;        // set only once every layer's chain has been enqueued: an error return below must not
+                              // leave a half-built factorisation marked as current
   HIPCHK(hipMemsetAsync(ctx->scal, 0, 4 * sizeof(double), ctx->st));
-  LayerFork fork(ctx, (int)ctx->L.size());
+  const bool ov = overlap && ctx->use_side && ctx->L.size() > 1 && ctx->L.size() <= (size_t)dgp_ctx::kMaxEv && ctx->ev_prep[0] != nullptr;
+  hipStream_t main_st = ctx->st;
+  if (ov) {
+    HIPCHK(hipEventRecord(ctx->ev_fork, main_st));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0));
+  }
+  {
+  LayerFork fork(ctx, ov ? 1 : (int)ctx->L.size());
   for (size_t li = 0; li < ctx->L.size(); ++li) {
     Layer& y = ctx->L[li];
-    fork.use((int)li);
+    if (ov) {
+      const int w = li == 0 ? 0 : 1 + (int)((li - 1) % 2);
+      ctx->st = w == 0 ? main_st : ctx->side[w - 1];
+      ctx->sm = ctx->smset[w];
+    } else {
+      fork.use((int)li);
+    }
+    struct Restore { dgp_ctx* c; hipStream_t m; bool on; size_t li; ~Restore() {
+      if (!on) return;
+      if (li > 0) { (void)hipEventRecord(c->ev_prep[li], c->st); c->prep_wait[li] = true; }
+      c->st = m; c->sm = c->smset[0]; } } restore{ctx, main_st, ov, li};
     const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
     const long MM = (long)Mp * Mp;
     HIPCHK(pack_q(ctx->st, P(ctx, y.off_qsqrt), P(ctx, y.off_qmu), M, Mp, D, y.Lq, y.qmu_p));
@@ -476,6 +526,8 @@ int prep(dgp_ctx* ctx, bool train = false) {
       HIPCHK(make_z1(ctx->st, P(ctx, y.off_Z), M, Mp, Din, y.Z1));
     }
   }
+  }   // the fork has joined the side streams
+  ctx->prep_level = train ? 2 : 1;
   return DGP_OK;
 }
 
@@ -500,6 +552,10 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
     const long Pl = dedup ? Nc : (long)S * Nc, Pm = pad_rows(Pl);
     const double* Xin = dedup ? Xsrc : ctx->L[l - 1].F;
     const long row0 = dedup ? n0 : 0;
+    if (l < dgp_ctx::kMaxEv && ctx->prep_wait[l]) {     // this layer's Kuu chain was left running on a side stream
+      HIPCHK(hipStreamWaitEvent(ctx->st, ctx->ev_prep[l], 0));
+      ctx->prep_wait[l] = false;
+    }
     const double tri1 = (double)Pl * Mp * (Mp + 1.0);   // 2 * M(M+1)/2 flops per point
     // c = Lu^-1 k (|c|^2 partials) and t_d = W_d^T c (|t_d|^2 partials always leave the kernel; t_d itself only for
     // the backward pass, store_t).  Both run on the wide-tile kernel (gemm_wide.h: 2 partial planes per 256 columns)
@@ -548,6 +604,7 @@ struct BwdOpts {
   long n_goff;
   bool params;
   bool xgrad0;
+  int (*after_layer)(dgp_ctx*, int) = nullptr;   // called when the backward pass has left layer l (its sums are final)
 };
 
 int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool use_zs, const BwdOpts& o) {
@@ -637,6 +694,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
                               zsrc_of(ctx, l - 1, use_zs, seed, o.n_goff, o.Ntot), n0, w.mbar, w.vbar,
                               o.params ? acc + w.acc_dvar : nullptr));
     }
+    if (o.after_layer) RET(o.after_layer(ctx, l));
   }
   return DGP_OK;
 }

@@ -21,7 +21,8 @@ SYMBOLS = [
     "dgp_create", "dgp_destroy", "dgp_last_error", "dgp_sync", "dgp_device_info", "dgp_model_set", "dgp_param_count",
     "dgp_params_get", "dgp_params_set", "dgp_data_set", "dgp_set_workspace_limit", "dgp_batch_set", "dgp_elbo", "dgp_propagate",
     "dgp_propagate_vjp", "dgp_vjp_accumulate", "dgp_propagate_full_cov", "dgp_gpr_lml", "dgp_gpr_predict", "dgp_gpr_predict_vjp",
-    "dgp_grad_partial", "dgp_acc_info", "dgp_acc_bind", "dgp_grad_finish", "dgp_grad_get", "dgp_last_elbo",
+    "dgp_grad_partial", "dgp_acc_info", "dgp_acc_bind", "dgp_grad_finish", "dgp_grad_get", "dgp_last_elbo", "dgp_grad_step",
+    "dgp_comm_unique_id", "dgp_comm_init", "dgp_comm_destroy", "dgp_comm_allreduce",
     "dgp_adam_reset", "dgp_adam_step", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_dev_gemm",
     "dgp_dev_chol", "dgp_dev_trinv", "dgp_dev_normals", "dgp_dev_mfma_peak",
 ]
@@ -89,6 +90,11 @@ def load():
         "dgp_grad_finish": (C.c_int, [vp, _dp]),
         "dgp_grad_get": (C.c_int, [vp, _dp]),
         "dgp_last_elbo": (C.c_int, [vp, _dp]),
+        "dgp_grad_step": (C.c_int, [vp, i32, u64, _dpp, _dp]),
+        "dgp_comm_unique_id": (C.c_int, [vp]),
+        "dgp_comm_init": (C.c_int, [vp, i32, i32, vp]),
+        "dgp_comm_destroy": (C.c_int, [vp]),
+        "dgp_comm_allreduce": (C.c_int, [vp, vp, i64]),
         "dgp_adam_reset": (C.c_int, [vp]),
         "dgp_adam_step": (C.c_int, [vp, dbl, dbl, dbl, dbl, C.POINTER(C.c_uint8)]),
         "dgp_natgrad_step": (C.c_int, [vp, dbl, C.POINTER(C.c_uint8)]),
@@ -180,6 +186,7 @@ class Context:
         X, Y = _c(X), _c(Y)
         self._chk(self._lib.dgp_data_set(self._h, _ptr(X), _ptr(Y), X.shape[0], X.shape[1], Y.shape[1],
                                          int(n_global_offset)))
+        self.n_data = X.shape[0]
 
     def batch_set(self, start=0, count=0, scale=1.0):
         """Evaluate the bound on the resident points [start, start+count) with the data term times `scale`
@@ -190,14 +197,22 @@ class Context:
         self._chk(self._lib.dgp_set_workspace_limit(self._h, int(nbytes)))
 
     # ---- forward --------------------------------------------------------------------------
-    def _zs(self, zs):
+    def _zs(self, zs, S=None, N=None):
+        """Injected normals: one [S, N, D_l] array per layer.  The library copies S*N*D_l doubles from each pointer, so
+        a wrongly shaped array would be an out-of-bounds read: reject it here (the reference would raise a shape error)."""
         if zs is None:
             return None, None
         keep = [_c(z) for z in zs]
+        if len(keep) != self.n_layers:
+            raise ValueError(f"zs: expected {self.n_layers} arrays (one per layer), got {len(keep)}")
+        for l, z in enumerate(keep):
+            want = (S, N, self.douts[l])
+            if z.ndim != 3 or z.shape[2] != want[2] or (S is not None and z.shape[0] != S) or (N is not None and z.shape[1] != N):
+                raise ValueError(f"zs[{l}]: expected shape {want}, got {z.shape}")
         return _ptr_array(keep), keep
 
     def elbo(self, S, seed=0, zs=None):
-        zp, keep = self._zs(zs)
+        zp, keep = self._zs(zs, S, getattr(self, "n_data", None))
         a, b = C.c_double(), C.c_double()
         self._chk(self._lib.dgp_elbo(self._h, int(S), int(seed) & (2 ** 64 - 1), zp, C.byref(a), C.byref(b)))
         return a.value, b.value
@@ -205,7 +220,7 @@ class Context:
     def propagate(self, Xnew, S, seed=0, zs=None, want=(True, True, True), add_lik_var=False):
         Xnew = _c(Xnew)
         Nn = Xnew.shape[0]
-        zp, keep = self._zs(zs)
+        zp, keep = self._zs(zs, S, Nn)
         outs = []
         for w in want:
             outs.append([np.empty((S, Nn, d)) if w else None for d in self.douts])
@@ -220,10 +235,12 @@ class Context:
         """full_cov=True propagation (dgp_propagate_full_cov): Fvars are [S, Nn, Nn, D_l]."""
         Xnew = _c(Xnew)
         Nn = Xnew.shape[0]
-        zp, keep = self._zs(zs)
+        zp, keep = self._zs(zs, S, Nn)
         Fs = [np.empty((S, Nn, d)) for d in self.douts]
         Fm = [np.empty((S, Nn, d)) for d in self.douts]
         Fv = [np.empty((S, Nn, Nn, d)) for d in self.douts]
+        if Nn == 0:          # no points: empty results, as propagate() returns
+            return Fs, Fm, Fv
         self._chk(self._lib.dgp_propagate_full_cov(self._h, _ptr(Xnew), Nn, int(S), int(seed) & (2 ** 64 - 1), zp,
                                                    _ptr_array(Fs), _ptr_array(Fm), _ptr_array(Fv)))
         return Fs, Fm, Fv
@@ -263,7 +280,7 @@ class Context:
         accumulator, cleared first or not (dgp_vjp_accumulate; finish with grad_finish / grad_get)."""
         Xnew = _c(Xnew)
         Nn = Xnew.shape[0]
-        zp, keep = self._zs(zs)
+        zp, keep = self._zs(zs, S, Nn)
         shape = (S, Nn, self.douts[-1])
         bars = []
         for b in (f_bar, mean_bar, var_bar):
@@ -286,7 +303,7 @@ class Context:
 
     # ---- backward + optimisers --------------------------------------------------------------
     def grad_partial(self, S, seed=0, zs=None):
-        zp, keep = self._zs(zs)
+        zp, keep = self._zs(zs, S, getattr(self, "n_data", None))
         self._chk(self._lib.dgp_grad_partial(self._h, int(S), int(seed) & (2 ** 64 - 1), zp))
 
     def acc_info(self):
@@ -296,6 +313,39 @@ class Context:
 
     def acc_bind(self, dev_ptr):
         self._chk(self._lib.dgp_acc_bind(self._h, C.c_void_p(dev_ptr) if dev_ptr else None))
+
+    def grad_step(self, S, seed=0, zs=None, want_elbo=False):
+        """grad_partial + all-reduce (when comm_init was called) + grad_finish in one overlapped call (dgp_grad_step)."""
+        zp, keep = self._zs(zs, S, getattr(self, "n_data", None))
+        if want_elbo:
+            e = C.c_double()
+            self._chk(self._lib.dgp_grad_step(self._h, int(S), int(seed) & (2 ** 64 - 1), zp, C.byref(e)))
+            return e.value
+        self._chk(self._lib.dgp_grad_step(self._h, int(S), int(seed) & (2 ** 64 - 1), zp, None))
+        return None
+
+    # ---- multi-GPU: library-owned RCCL communicator ---------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes (ncclUniqueId) from rank 0, to be broadcast to the other ranks by the host."""
+        lib = load()
+        buf = C.create_string_buffer(128)
+        rc = lib.dgp_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != DGP_OK:
+            raise NativeError(rc, "dgp_comm_unique_id failed (librccl.so not loadable?)")
+        return bytes(buf.raw)
+
+    def comm_init(self, rank, world, unique_id=None):
+        buf = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+        self._chk(self._lib.dgp_comm_init(self._h, int(rank), int(world), C.cast(buf, C.c_void_p) if buf is not None else None))
+        self.comm_world = int(world)
+
+    def comm_destroy(self):
+        self._chk(self._lib.dgp_comm_destroy(self._h))
+        self.comm_world = 1
+
+    def comm_allreduce(self, dev_ptr, n):
+        self._chk(self._lib.dgp_comm_allreduce(self._h, C.c_void_p(dev_ptr), int(n)))
 
     def grad_finish(self, want_elbo=False):
         if want_elbo:

@@ -100,6 +100,13 @@ class DGP_Base:
             dev = self._device if self._device is not None else (self._dist.local_device() if self._dist else 0)
             stream = self._dist.stream_handle(dev) if self._dist else None
             self._ctx = _native.Context(dev, stream)
+            self._native_comm = False
+            if self._dist and self._dist.native_comm():
+                # the library owns an RCCL communicator: rank 0's unique id travels through the process group once
+                uid = _native.Context.comm_unique_id() if self._dist.rank == 0 else bytes(128)
+                uid = self._dist.broadcast_bytes(uid, dev)
+                self._ctx.comm_init(self._dist.rank, self._dist.world, uid)
+                self._native_comm = True
         return self._ctx
 
     def _sync_model(self):
@@ -227,10 +234,15 @@ class DGP_Base:
         ctx = self._sync_model()
         self._sync_data(data)
         self._select_batch(ctx, True)
-        ctx.grad_partial(self.num_samples, self._next_seed(), None)
-        if self._dist:
+        if self._dist and not getattr(self, "_native_comm", False):
+            # collective owned by the process group (gloo rehearsals, or when the library's own communicator is switched off):
+            # three stages with the reduce between them
+            ctx.grad_partial(self.num_samples, self._next_seed(), None)
             self._dist.all_reduce_(self._acc_tensor)
-        ctx.grad_finish()
+            ctx.grad_finish()
+        else:
+            # one call: per-layer all-reduce (when sharded) and small-matrix chains overlap the backward pass
+            ctx.grad_step(self.num_samples, self._next_seed(), None)
         return ctx
 
     def _say(self, msg):

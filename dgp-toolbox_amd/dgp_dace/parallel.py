@@ -57,8 +57,18 @@ class Dist:
         return self._stream.cuda_stream
 
     def device_buffer(self, n, dev):
-        device = f"cuda:{dev}" if self.on_gpu else "cpu"
-        return self.torch.zeros(int(n), dtype=self.torch.float64, device=device)
+        """Zero-filled fp64 buffer.  On a GPU it is allocated and filled on the stream the native context launches on, so
+        the fill is ordered before every kernel that accumulates into it (the default stream would not be)."""
+        if not self.on_gpu:
+            return self.torch.zeros(int(n), dtype=self.torch.float64, device="cpu")
+        if self._stream is None:
+            t = self.torch.zeros(int(n), dtype=self.torch.float64, device=f"cuda:{dev}")
+            self.torch.cuda.current_stream(dev).synchronize()
+            return t
+        with self.torch.cuda.stream(self._stream):
+            t = self.torch.zeros(int(n), dtype=self.torch.float64, device=f"cuda:{dev}")
+        t.record_stream(self._stream)
+        return t
 
     def all_reduce_(self, t):
         """In-place sum over ranks of the partial-sum buffer (RCCL ring over xGMI on GPUs)."""
@@ -81,6 +91,20 @@ class Dist:
 
     def barrier(self):
         self.dist.barrier()
+
+    def native_comm(self):
+        """True when the library should own the collective (dgp_comm_init, RCCL on its own streams): the `nccl` backend
+        unless DGP_COMM=torch.  With gloo (CPU tests, one-GPU rehearsals) the reduce stays in torch.distributed."""
+        return self.dist.get_backend() == "nccl" and os.environ.get("DGP_COMM", "native") != "torch"
+
+    def broadcast_bytes(self, payload, dev):
+        """Rank 0's `payload` (bytes) on every rank, through the process group (a uint8 tensor on the group's device)."""
+        n = len(payload)
+        device = f"cuda:{dev}" if self.dist.get_backend() == "nccl" else "cpu"
+        t = self.torch.tensor(list(payload), dtype=self.torch.uint8, device=device) if self.rank == 0 else \
+            self.torch.zeros(n, dtype=self.torch.uint8, device=device)
+        self.dist.broadcast(t, src=0)
+        return bytes(t.cpu().tolist())
 
 
 def current():

@@ -87,15 +87,21 @@ class SVGP_Layer(Layer):
         return self._private
 
     def conditional_ND(self, X, full_cov=False):
-        if full_cov:
-            raise NotImplementedError("full_cov=True (layers.py:265-268) is a listed next row, not implemented")
+        """layers.py:236-278.  full_cov=True: mean [N, D], var [N, N, D] (the reference transposes [D, N, N])."""
         X = np.ascontiguousarray(X, dtype=np.float64)
+        if full_cov:
+            _, Fm, Fv = self._ctx().propagate_full_cov(X, 1, 0, None)
+            return as_tensor(Fm[0][0]), as_tensor(Fv[0][0])
         _, Fm, Fv = self._ctx().propagate(X, 1, 0, None, want=(False, True, True))
         return as_tensor(Fm[0][0]), as_tensor(Fv[0][0])
 
     def conditional_SND(self, X, full_cov=False):
+        """layers.py:63-85: full_cov=True maps conditional_ND over the samples (var [S, N, N, D])."""
         S, N, D = X.shape
-        mean, var = self.conditional_ND(np.reshape(X, (S * N, D)), full_cov=full_cov)
+        if full_cov:
+            ms, vs = zip(*[self.conditional_ND(np.asarray(X[s]), full_cov=True) for s in range(S)])
+            return [as_tensor(np.stack([np.asarray(m) for m in ms])), as_tensor(np.stack([np.asarray(v) for v in vs]))]
+        mean, var = self.conditional_ND(np.reshape(X, (S * N, D)))
         return [as_tensor(np.reshape(m, (S, N, self.num_outputs))) for m in (mean, var)]
 
     def sample_from_conditional(self, X, z=None, full_cov=False):

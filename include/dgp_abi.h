@@ -157,6 +157,25 @@ int dgp_acc_bind(dgp_ctx* ctx, void* external_device_ptr);   /* use caller-owned
 int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out /* NULL = do not synchronise */);
 int dgp_grad_get(dgp_ctx* ctx, double* flat_grad_out);       /* d ELBO / d constrained params, same packing */
 int dgp_last_elbo(dgp_ctx* ctx, double* elbo_out);           /* ELBO of the last dgp_grad_finish (synchronises) */
+/* dgp_grad_partial + (all-reduce) + dgp_grad_finish as ONE call that overlaps them: the loop body of dgp.py:271-275
+ * (one `tape.gradient(-ELBO)` evaluation).  As soon as the backward pass leaves layer l, that layer's slice of the
+ * partial-sum buffer is summed over the ranks (when dgp_comm_init was called; on the library's own streams) and the
+ * layer's small-matrix chain runs, while the layers below are still in their backward pass; the Kuu factorisations of
+ * the layers above the first also run under the first layer's forward pass.  Results are those of the three-call
+ * sequence.  elbo_out NULL = do not synchronise.                                                                    */
+int dgp_grad_step(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs, double* elbo_out);
+
+/* ---- multi-GPU: one process per GPU, the data points sharded (dgp.py:87,96 are sums over points).  The reference has
+ * no multi-device code.  The library owns an RCCL communicator (librccl is loaded with dlopen,
+ * the process's existing copy when torch has loaded one) so that dgp_grad_step can enqueue its all-reduces itself,
+ * without a host round trip between the backward pass and the small-matrix chains.
+ *   dgp_comm_unique_id : rank 0 fills 128 bytes (ncclUniqueId); the host broadcasts them to the other ranks
+ *   dgp_comm_init      : every rank, same id; world == 1 is accepted (no communicator is created)
+ *   dgp_comm_allreduce : in-place sum of n doubles at a DEVICE pointer, on the context's stream (test / utility)      */
+int dgp_comm_unique_id(void* id128_out);
+int dgp_comm_init(dgp_ctx* ctx, int32_t rank, int32_t world, const void* id128);
+int dgp_comm_destroy(dgp_ctx* ctx);
+int dgp_comm_allreduce(dgp_ctx* ctx, void* device_ptr, int64_t n_doubles);
 
 /* tf.optimizers.Adam on the unconstrained variables (dgp.py:267,276; 311,333,342).
  * trainable: 5*n_layers+1 flags in the order [Z, variance, lengthscales, q_mu, q_sqrt]*, lik variance

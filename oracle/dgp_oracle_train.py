@@ -26,6 +26,7 @@ class OracleTrainer:
             for k in ("Z", "variance", "lengthscales", "q_mu", "q_sqrt"):
                 self.trainable[(i, k)] = True
         self.trainable[("lik", "variance")] = True
+        self.grad_hook = None
 
     # -- helpers -----------------------------------------------------------------------
     def _next_zs(self):
@@ -85,6 +86,8 @@ class OracleTrainer:
         for i, g in enumerate(G["layers"]):
             for k, v in g.items():
                 flat[(i, k)] = v
+        if self.grad_hook is not None:      # tests only: e.g. rounding-level noise on chosen entries (tests/test_oracle.py)
+            self.grad_hook(flat)
         return elbo, flat
 
     # -- dgp.py:255-278 ------------------------------------------------------------------
