@@ -624,8 +624,9 @@ int dgp_comm_init(dgp_ctx* ctx, int32_t rank, int32_t world, const void* id128) 
   RET(dgp_comm_destroy(ctx));
   ctx->comm_rank = rank;
   ctx->comm_world = world;
-  if (world == 1) return DGP_OK;
+  if (world == 1 && !id128) return DGP_OK;      // single process: nothing to reduce
   if (!id128) return fail(ctx, DGP_ERR_INVALID, "dgp_comm_init: no unique id");
+  // (world == 1 WITH an id builds a one-rank communicator: the whole RCCL path can then be exercised on one GPU)
   RET(nccl_load(ctx));
   HIPCHK(hipSetDevice(ctx->device));
   ncclUniqueIdBytes id;
@@ -650,7 +651,7 @@ int dgp_comm_destroy(dgp_ctx* ctx) {
 
 int dgp_comm_allreduce(dgp_ctx* ctx, void* device_ptr, int64_t n_doubles) {
   if (!ctx || !device_ptr || n_doubles < 0) return fail(ctx, DGP_ERR_INVALID, "dgp_comm_allreduce: bad argument");
-  if (ctx->comm_world <= 1 || n_doubles == 0) return DGP_OK;
+  if (n_doubles == 0 || (ctx->comm_world <= 1 && !ctx->nccl_comm)) return DGP_OK;
   if (!ctx->nccl_comm) return fail(ctx, DGP_ERR_INVALID, "dgp_comm_allreduce: call dgp_comm_init first");
   return nccl_chk(ctx, g_nccl.AllReduce(device_ptr, device_ptr, (size_t)n_doubles, kNcclFloat64, kNcclSum, ctx->nccl_comm, ctx->st),
                   "ncclAllReduce");
@@ -663,7 +664,7 @@ int after_layer_hook(dgp_ctx* ctx, int l) {
   const int nl = (int)ctx->L.size();
   Layer& y = ctx->L[l];
   const long lo = y.acc_Q, hi = (l + 1 < nl) ? ctx->L[l + 1].acc_Q : ctx->n_acc;     // the layer's contiguous slice
-  const bool comm = ctx->comm_world > 1 && ctx->nccl_comm != nullptr;
+  const bool comm = ctx->nccl_comm != nullptr;
   const bool side = ctx->use_side && nl <= dgp_ctx::kMaxEv && ctx->ev_layer[0] != nullptr;
   hipStream_t main_st = ctx->st;
   hipStream_t st = main_st;

@@ -373,16 +373,28 @@ hipError_t sub_identity(hipStream_t st, double* S, int M, int Mp, int batch) {
   LAUNCH_CHECK();
 }
 
-__global__ void symmetrize_lower_kernel(double* __restrict__ G, int Mp, long total) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const long b = idx / ((long)Mp * Mp);
-  const int i = (int)((idx / Mp) % Mp), j = (int)(idx % Mp);
-  if (j > i) G[idx] = G[b * Mp * Mp + (long)j * Mp + i];
+// G (lower triangle valid) -> symmetric: tile (bi, bj) with bj > bi takes the transpose of tile (bj, bi) through LDS
+// (coalesced reads and writes; the element-wise version read G column-wise right after the atomics of the Gram product
+// had left it in HBM: 167 us for 8 x 256^2, on the critical path of the last layer's chain), diagonal tiles in place.
+__global__ __launch_bounds__(256) void symmetrize_lower_kernel(double* __restrict__ G, int Mp) {
+  __shared__ double tile[32][33];
+  const int nb = Mp / 32;
+  // enumerate the pairs bi <= bj
+  int t = blockIdx.x, bi = 0;
+  while (t >= nb - bi) { t -= nb - bi; ++bi; }
+  const int bj = bi + t;
+  double* __restrict__ Gb = G + (long)blockIdx.y * Mp * Mp;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = Gb[(long)(bj * 32 + r) * Mp + bi * 32 + tx];     // lower tile (bj, bi)
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    if (j > i) Gb[(long)i * Mp + j] = tile[tx][r];
+  }
 }
 hipError_t symmetrize_lower(hipStream_t st, double* G, int Mp, int batch) {
-  const long n = (long)batch * Mp * Mp;
-  hipLaunchKernelGGL(symmetrize_lower_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G, Mp, n);
+  const int nb = Mp / 32;
+  hipLaunchKernelGGL(symmetrize_lower_kernel, dim3((unsigned)(nb * (nb + 1) / 2), (unsigned)batch), dim3(256), 0, st, G, Mp);
   LAUNCH_CHECK();
 }
 

@@ -102,11 +102,26 @@ class DGP_Base:
             self._ctx = _native.Context(dev, stream)
             self._native_comm = False
             if self._dist and self._dist.native_comm():
-                # the library owns an RCCL communicator: rank 0's unique id travels through the process group once
-                uid = _native.Context.comm_unique_id() if self._dist.rank == 0 else bytes(128)
+                # the library owns an RCCL communicator: rank 0's unique id travels through the process group once.
+                # Every rank must end up on the same path, so a failure anywhere (librccl not loadable, init error) is
+                # agreed on through the group and all ranks keep the process group's collective instead.
+                ok = 1.0
+                try:
+                    uid = _native.Context.comm_unique_id() if self._dist.rank == 0 else bytes(128)
+                except Exception as e:           # noqa: BLE001
+                    uid, ok = bytes(128), 0.0
+                    self._say_err(f"dgp_comm_unique_id failed ({e}); using the process group's all-reduce")
                 uid = self._dist.broadcast_bytes(uid, dev)
-                self._ctx.comm_init(self._dist.rank, self._dist.world, uid)
-                self._native_comm = True
+                if self._dist.all_reduce_min(ok, dev) > 0.5:
+                    try:
+                        self._ctx.comm_init(self._dist.rank, self._dist.world, uid)
+                    except Exception as e:       # noqa: BLE001
+                        ok = 0.0
+                        self._say_err(f"dgp_comm_init failed ({e}); using the process group's all-reduce")
+                    if self._dist.all_reduce_min(ok, dev) > 0.5:
+                        self._native_comm = True
+                    else:
+                        self._ctx.comm_destroy()
         return self._ctx
 
     def _sync_model(self):
@@ -244,6 +259,10 @@ class DGP_Base:
             # one call: per-layer all-reduce (when sharded) and small-matrix chains overlap the backward pass
             ctx.grad_step(self.num_samples, self._next_seed(), None)
         return ctx
+
+    def _say_err(self, msg):
+        import sys
+        print(f"[dgp rank {self._dist.rank if self._dist else 0}] {msg}", file=sys.stderr, flush=True)
 
     def _say(self, msg):
         if not self._dist or self._dist.rank == 0:

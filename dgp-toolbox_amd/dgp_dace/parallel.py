@@ -89,13 +89,22 @@ class Dist:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_reduce_min(self, v, dev=0):
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=(f"cuda:{dev}" if self.on_gpu else "cpu"))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
+
     def barrier(self):
         self.dist.barrier()
 
     def native_comm(self):
         """True when the library should own the collective (dgp_comm_init, RCCL on its own streams): the `nccl` backend
-        unless DGP_COMM=torch.  With gloo (CPU tests, one-GPU rehearsals) the reduce stays in torch.distributed."""
-        return self.dist.get_backend() == "nccl" and os.environ.get("DGP_COMM", "native") != "torch"
+        unless DGP_COMM=torch.  With gloo (CPU tests, one-GPU rehearsals) the reduce stays in torch.distributed unless
+        DGP_COMM=native asks for the library's communicator there too."""
+        mode = os.environ.get("DGP_COMM", "auto")      # auto | native (also under gloo: rehearsals) | torch
+        if mode == "native":
+            return self.on_gpu
+        return mode != "torch" and self.dist.get_backend() == "nccl"
 
     def broadcast_bytes(self, payload, dev):
         """Rank 0's `payload` (bytes) on every rank, through the process group (a uint8 tensor on the group's device)."""

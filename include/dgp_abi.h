@@ -170,7 +170,8 @@ int dgp_grad_step(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* z
  * the process's existing copy when torch has loaded one) so that dgp_grad_step can enqueue its all-reduces itself,
  * without a host round trip between the backward pass and the small-matrix chains.
  *   dgp_comm_unique_id : rank 0 fills 128 bytes (ncclUniqueId); the host broadcasts them to the other ranks
- *   dgp_comm_init      : every rank, same id; world == 1 is accepted (no communicator is created)
+ *   dgp_comm_init      : every rank, same id; world == 1 with id128 == NULL creates no communicator (nothing to reduce),
+ *                        world == 1 with an id creates a one-rank communicator (exercises the RCCL path on one GPU)
  *   dgp_comm_allreduce : in-place sum of n doubles at a DEVICE pointer, on the context's stream (test / utility)      */
 int dgp_comm_unique_id(void* id128_out);
 int dgp_comm_init(dgp_ctx* ctx, int32_t rank, int32_t world, const void* id128);

@@ -214,6 +214,19 @@ def test_grad_step_equals_partial_reduce_finish():
     e2 = ctx.grad_step(int(g["S"]), 0, zs, want_elbo=True)
     assert abs(e2 - e0) <= 1e-13 * abs(e0)
     np.testing.assert_allclose(ctx.grad_get(), g0, rtol=1e-12, atol=1e-12 * np.abs(g0).max())
+    # a ONE-rank RCCL communicator owned by the library (dlopen of librccl, ncclCommInitRank, grouped ncclAllReduce per
+    # layer on the side streams): the sum over one rank is the identity, so the result must not move
+    from dgp_dace._native import Context
+    ctx.comm_init(0, 1, Context.comm_unique_id())
+    e3 = ctx.grad_step(int(g["S"]), 0, zs, want_elbo=True)
+    assert abs(e3 - e0) <= 1e-13 * abs(e0)
+    np.testing.assert_allclose(ctx.grad_get(), g0, rtol=1e-12, atol=1e-12 * np.abs(g0).max())
+    import torch
+    t = torch.arange(1000, dtype=torch.float64, device="cuda")
+    ctx.comm_allreduce(t.data_ptr(), t.numel())
+    ctx.sync()
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
+    ctx.comm_destroy()
     with pytest.raises(ValueError):
         ctx.grad_step(int(g["S"]), 0, zs[:-1])                 # wrong number of injected arrays
     with pytest.raises(ValueError):
