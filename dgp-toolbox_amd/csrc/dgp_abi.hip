@@ -67,6 +67,8 @@ void dgp_destroy(dgp_ctx* ctx) {
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   (void)dgp_comm_destroy(ctx);
+  drop_graph(ctx);
+  dev_free(ctx->it_dev); dev_free(ctx->elbo_log);
   for (int i = 0; i < dgp_ctx::kMaxEv; ++i) {
     if (ctx->ev_prep[i]) (void)hipEventDestroy(ctx->ev_prep[i]);
     if (ctx->ev_layer[i]) (void)hipEventDestroy(ctx->ev_layer[i]);
@@ -201,6 +203,7 @@ int dgp_params_set(dgp_ctx* ctx, const double* flat_in) {
 }
 
 int dgp_data_set(dgp_ctx* ctx, const double* X, const double* Y, int64_t N, int32_t D, int32_t Dy, int64_t n_global_offset) {
+  if (ctx) drop_graph(ctx);
   if (!ctx || !X || !Y || N <= 0 || D <= 0 || Dy <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_data_set: bad arguments");
   HIPCHK(hipStreamSynchronize(ctx->st));
   dev_free(ctx->X); dev_free(ctx->Y);
@@ -770,6 +773,12 @@ int dgp_adam_step(dgp_ctx* ctx, double lr, double beta_1, double beta_2, double 
   }
   ctx->prep_level = 0;
   ctx->adam_t += 1;
+  if (ctx->capturing) {          // inside the captured iteration: the step count lives in device memory
+    HIPCHK(iter_bump(ctx->st, ctx->it_dev, 0, 1));
+    HIPCHK(adam_apply(ctx->st, ctx->params, ctx->grad, ctx->adam_m, ctx->adam_v, ctx->segs_dev, (int)ctx->segs.size(),
+                      ctx->n_params, lr, beta_1, beta_2, epsilon, ctx->it_dev + 1));
+    return DGP_OK;
+  }
   const double t = (double)ctx->adam_t;
   const double lr_t = lr * std::sqrt(1.0 - std::pow(beta_2, t)) / (1.0 - std::pow(beta_1, t));
   ProfScope ps(ctx, 3, 0, (double)ctx->n_params * 48);
@@ -804,6 +813,131 @@ int dgp_natgrad_step(dgp_ctx* ctx, double gamma, const uint8_t* layer_mask) {
     HIPCHK(potrf_inv(ctx->st, y.Lq, ctx->sm[8], ctx->sm[9], Mp, D, ctx->info));
     HIPCHK(store_q(ctx->st, y.Lq, y.qmu_p, M, Mp, D, ctx->params + y.off_qsqrt, ctx->params + y.off_qmu));
   }
+  return DGP_OK;
+}
+
+// One loop body of DGP.optimize_adam (dgp.py:271-276) or of part 2 of DGP.optimize_nat_adam (dgp.py:326-345).
+static int train_iteration(dgp_ctx* ctx, int32_t S, uint64_t seed, double lr, double b1, double b2, double eps,
+                           const uint8_t* trainable, double gamma, const uint8_t* layer_mask) {
+  RET(dgp_grad_step(ctx, S, seed, nullptr, nullptr));
+  if (ctx->capturing) HIPCHK(iter_bump(ctx->st, ctx->it_dev, 1, 0));             // next evaluation: next seed
+  RET(dgp_adam_step(ctx, lr, b1, b2, eps, trainable));
+  if (ctx->capturing) HIPCHK(iter_log_elbo(ctx->st, ctx->it_dev, ctx->scal, ctx->elbo_log, dgp_ctx::kLogCap));
+  if (gamma > 0.0) {
+    RET(dgp_grad_step(ctx, S, seed + 1, nullptr, nullptr));
+    if (ctx->capturing) HIPCHK(iter_bump(ctx->st, ctx->it_dev, 1, 0));
+    RET(dgp_natgrad_step(ctx, gamma, layer_mask));
+  }
+  return DGP_OK;
+}
+
+int dgp_adam_iterations(dgp_ctx* ctx, int32_t n_iter, int32_t S, uint64_t seed0, double lr, double beta_1, double beta_2,
+                        double epsilon, const uint8_t* trainable, double gamma, const uint8_t* layer_mask,
+                        int32_t use_graph, double* elbo_out) {
+  RET(check_ready(ctx, true));
+  if (n_iter < 0 || S <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_adam_iterations: bad n_iter / S");
+  if (n_iter == 0) return DGP_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int per = gamma > 0.0 ? 2 : 1;                      // ELBO evaluations (= seeds) per iteration
+  const int nseg = (int)ctx->segs.size(), nl = (int)ctx->L.size();
+  // launch-bound models (the Bayesian-optimisation workloads: tens of inducing points, ~120 launches of a few
+  // microseconds per iteration): capture ONE iteration into a hipGraph and replay it.
+  // Measured on MI355X / ROCm 7.2 (tools/small_model_bench.py): the replayed graph is SLOWER than the call-by-call
+  // launches (config 1: 0.81 against 0.75 ms per iteration; notebook model 0.90 against 0.77) -- the replay runs the
+  // captured side-stream branches one after the other, and these iterations are bound by the dependent chain of ~85
+  // kernels of 4-15 us, not by the host's launch rate.  So -1 ("by size") currently means "no"; 1 or DGP_GRAPH=1 asks
+  // for the graph.
+  bool graph = use_graph > 0;
+  {
+    static int env = -2;
+    if (env == -2) { const char* e = getenv("DGP_GRAPH"); env = e ? atoi(e) : -1; }
+    if (env == 0) graph = false;
+    if (env > 0 && use_graph != 0) graph = true;
+  }
+  if (ctx->prof.on || ctx->nccl_comm || ctx->comm_world > 1 || n_iter < 3 || !ctx->use_side) graph = false;
+  std::vector<double> elbos((size_t)n_iter, 0.0);
+  // one iteration launched call by call; the ELBO the iteration would print is read back only when asked for
+  auto eager_iter = [&](int i) -> int {
+    const uint64_t sd = seed0 + (uint64_t)per * i;
+    RET(dgp_grad_step(ctx, S, sd, nullptr, nullptr));
+    RET(dgp_adam_step(ctx, lr, beta_1, beta_2, epsilon, trainable));
+    if (elbo_out) RET(dgp_last_elbo(ctx, &elbos[i]));
+    if (per == 2) {
+      RET(dgp_grad_step(ctx, S, sd + 1, nullptr, nullptr));
+      RET(dgp_natgrad_step(ctx, gamma, layer_mask));
+    }
+    return DGP_OK;
+  };
+  int done = 0;
+  if (graph) {
+    if (!ctx->it_dev) { RET(dev_alloc(ctx, &ctx->it_dev, 4)); RET(dev_alloc(ctx, &ctx->elbo_log, dgp_ctx::kLogCap)); }
+    char keybuf[512];
+    snprintf(keybuf, sizeof keybuf, "S%d N%ld b%ld+%ld s%.17g lr%.17g b1%.17g b2%.17g e%.17g g%.17g ws%p acc%p X%p ", S, ctx->N,
+             ctx->batch_lo, ctx->batch_n, ctx->data_scale, lr, beta_1, beta_2, epsilon, gamma, (void*)ctx->ws, (void*)ctx->acc,
+             (void*)ctx->X);
+    std::string key = keybuf;
+    for (int i = 0; i < nseg; ++i) key += (trainable ? (trainable[i] ? '1' : '0') : '1');
+    key += ' ';
+    for (int l = 0; l < nl; ++l) key += (layer_mask ? (layer_mask[l] ? '1' : '0') : '1');
+    if (!ctx->graph_exec || ctx->graph_key != key) {
+      drop_graph(ctx);
+      // one eager iteration first: allocations (workspace, scratch), the upload of the trainable flags and whatever else
+      // must not happen inside a capture; it is iteration 0 of this call
+      RET(eager_iter(0));
+      done = 1;
+      // (the workspace may just have been allocated: the key is built from the pointers as they are now)
+      snprintf(keybuf, sizeof keybuf, "S%d N%ld b%ld+%ld s%.17g lr%.17g b1%.17g b2%.17g e%.17g g%.17g ws%p acc%p X%p ", S, ctx->N,
+               ctx->batch_lo, ctx->batch_n, ctx->data_scale, lr, beta_1, beta_2, epsilon, gamma, (void*)ctx->ws, (void*)ctx->acc,
+               (void*)ctx->X);
+      key = keybuf;
+      for (int i = 0; i < nseg; ++i) key += (trainable ? (trainable[i] ? '1' : '0') : '1');
+      key += ' ';
+      for (int l = 0; l < nl; ++l) key += (layer_mask ? (layer_mask[l] ? '1' : '0') : '1');
+      HIPCHK(hipStreamSynchronize(ctx->st));
+      const long adam_t0 = ctx->adam_t;
+      ctx->capturing = true;
+      hipError_t e = hipStreamBeginCapture(ctx->st, hipStreamCaptureModeRelaxed);
+      int rc = DGP_OK;
+      if (e == hipSuccess) {
+        rc = train_iteration(ctx, S, 0, lr, beta_1, beta_2, epsilon, trainable, gamma, layer_mask);
+        hipGraph_t gph = nullptr;
+        e = hipStreamEndCapture(ctx->st, &gph);
+        ctx->graph = gph;
+      }
+      ctx->capturing = false;
+      ctx->adam_t = adam_t0;               // the captured launches did not run
+      ctx->prep_level = 0;
+      if (e != hipSuccess || rc != DGP_OK || !ctx->graph ||
+          hipGraphInstantiate(&ctx->graph_exec, ctx->graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        drop_graph(ctx);
+        graph = false;                     // capture refused: the call finishes call by call
+      } else {
+        ctx->graph_key = key;
+      }
+    }
+  }
+  if (!graph) {
+    for (int i = done; i < n_iter; ++i) RET(eager_iter(i));
+    if (elbo_out) memcpy(elbo_out, elbos.data(), sizeof(double) * n_iter);
+    return DGP_OK;
+  }
+  // device-side iteration state: seed of the next evaluation, Adam step count so far, index into the ELBO log
+  for (int base = done; base < n_iter; base += dgp_ctx::kLogCap) {
+    const int cnt = std::min(n_iter - base, (int)dgp_ctx::kLogCap);
+    double st[4] = {0.0, (double)ctx->adam_t, 0.0, 0.0};
+    const uint64_t sd = seed0 + (uint64_t)per * base;
+    memcpy(&st[0], &sd, 8);
+    HIPCHK(hipMemcpyAsync(ctx->it_dev, st, sizeof st, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));       // (st lives on this stack frame)
+    for (int i = 0; i < cnt; ++i) HIPCHK(hipGraphLaunch(ctx->graph_exec, ctx->st));
+    ctx->adam_t += cnt;
+    if (elbo_out) HIPCHK(hipMemcpyAsync(elbos.data() + base, ctx->elbo_log, sizeof(double) * cnt, hipMemcpyDeviceToHost, ctx->st));
+    RET(check_flags(ctx));                       // synchronises; a failed Cholesky inside the replays surfaces here
+  }
+  ctx->prep_level = 0;
+  ctx->grad_ready = true;
+  if (elbo_out) memcpy(elbo_out, elbos.data(), sizeof(double) * n_iter);
   return DGP_OK;
 }
 

@@ -94,6 +94,8 @@ hipError_t store_q(hipStream_t st, const double* Lq, const double* qmu_p, int M,
 struct ZSource {           // where the N(0,1) draws of one layer come from
   const double* zs;        // injected [S, Ntot, D] (device) or nullptr -> Philox
   uint64_t seed;
+  const uint64_t* seed_dev = nullptr;   // when set, the seed is read from device memory (captured-graph training loop:
+                                        // the launch arguments of a replayed graph cannot change)
   int layer;
   long n_global0;          // global index of local point 0 of the data set (Philox counter)
   long Ntot;               // row count of the injected array
@@ -159,8 +161,14 @@ hipError_t white_grad(hipStream_t st, const double* S, int M, int Mp, const doub
 // ---------------------------------------------------------------- optimiser kernels (optim.hip)
 enum Transform : int { TR_IDENTITY = 0, TR_SOFTPLUS = 1, TR_SOFTPLUS_SHIFT = 2, TR_TRIL = 3 };
 struct ParamSeg { long off, n; int transform; int trainable; int rows; };   // rows: M for TR_TRIL blocks
+// lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t): computed by the caller (t_dev == nullptr, `lr` is lr_t) or by the kernel from
+// the step count in device memory (captured-graph training loop)
 hipError_t adam_apply(hipStream_t st, double* params, const double* grad_elbo, double* m, double* v,
-                      const ParamSeg* segs_dev, int nseg, long total, double lr_t, double beta1, double beta2,
-                      double eps);
+                      const ParamSeg* segs_dev, int nseg, long total, double lr, double beta1, double beta2,
+                      double eps, const double* t_dev = nullptr);
+// device-side bookkeeping of the captured training iteration: it[0] = Philox seed (bits), it[1] = Adam step count,
+// it[2] = index into the ELBO log
+hipError_t iter_bump(hipStream_t st, double* it, int seed_inc, int t_inc);
+hipError_t iter_log_elbo(hipStream_t st, double* it, const double* scal, double* elbo_log, int cap);
 
 }  // namespace dgp

@@ -454,8 +454,9 @@ void gemm_wide_kernel(GemmArgs g) {
   // been issued -> wait for them and for the DMA of the next k-tile, barrier, request the next k-tile's first
   // fragments, run `pre_dma` (block-column epilogues whose stores should be OLDER than the next DMA requests), and
   // refill the stage just released with the k-tile three ahead.
-  auto ktile = [&](auto j0c, auto j1c, unsigned nb0, unsigned nb1, int first_of_block, int blk, auto&& pre_dma) __attribute__((always_inline)) {
+  auto ktile = [&](auto j0c, auto j1c, unsigned nb0, unsigned nb1, int first_of_block, int blk, auto&& pre_dma, auto fence_c) __attribute__((always_inline)) {
     constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+    constexpr bool FENCE = decltype(fence_c)::value;   // the last pair carries a block-column epilogue: keep its stores ahead of the DMA requests
     constexpr int NACT = J1 - J0 + 1, U = 4 * NACT;
     if constexpr (SCALED) {
       if (first_of_block) load_scales(blk);
@@ -498,13 +499,13 @@ void gemm_wide_kernel(GemmArgs g) {
       mma1(integral_constant<int, u0>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});
       constexpr int n_ds = lastp ? 6 : (((u0 + 2 < U) ? 4 : 0) + (p == 0 ? 2 : 0));
       if constexpr (lastp) {
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
         readA(0);
         readB(0, nb0);
         readB(1, nb1);
         pre_dma();
         issue(load, stage);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
       } else {
         {
           constexpr int u2 = u0 + 2, sub2 = u2 / NACT, j2 = J0 + u2 % NACT;
@@ -532,6 +533,21 @@ void gemm_wide_kernel(GemmArgs g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         });
         __builtin_amdgcn_sched_group_barrier(0x008, 15 - n_ds, 0);
+      } else if constexpr (!FENCE) {
+        // the k-tile's last pair: first MFMA, then the next k-tile's first fragment reads and the DMA requests of the
+        // k-tile three ahead, ONE per MFMA, so that their ~80 scalar / address instructions issue under the remaining
+        // MFMAs instead of in front of them (both waves of a SIMD are at this point together: nothing else would feed
+        // the matrix pipe meanwhile)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        w_static_for<0, 6>([&](auto) __attribute__((always_inline)) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        });
+        w_static_for<0, 6>([&](auto) __attribute__((always_inline)) {
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        });
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
       }
     });
     advance(load);
@@ -566,7 +582,7 @@ void gemm_wide_kernel(GemmArgs g) {
       const bool lastblk = blk == nkb - 1;
       if constexpr (DIR == 1) {
         const int nd = 16 * nq;
-        for (int t = 0; t < nd; ++t) { ktile(I0, I7, dn0, dn1, fob, blk, nothing); fob = 0; }
+        for (int t = 0; t < nd; ++t) { ktile(I0, I7, dn0, dn1, fob, blk, nothing, std::false_type{}); fob = 0; }
       }
       if constexpr (DIR != 0) {
         w_static_for<0, 16>([&](auto tc) __attribute__((always_inline)) {
@@ -599,8 +615,11 @@ void gemm_wide_kernel(GemmArgs g) {
                 epi_fast(integral_constant<int, (jw >= 0 ? jw : 0)>{}, DIR == 1 ? cons.tm : ptm, DIR == 1 ? cons.tn : ptn, DIR == 2 && t == 13, false);
             }
           };
-          if constexpr (DIR == 1) ktile(integral_constant<int, v>{}, I7, nb0, nb1, fob, blk, pre);
-          else ktile(I0, integral_constant<int, v>{}, nb0, nb1, fob, blk, pre);
+          // (measured: the interleaved last pair gains 1-2 % on Ct / dCt and loses 5 % on the T product, whose deferred
+          //  block-column stores share the vmcnt queue with the DMA requests: that kernel keeps the fenced form throughout)
+          constexpr bool has_epi = EM != 0 && (jw >= 0 || DIR == 2);
+          if constexpr (DIR == 1) ktile(integral_constant<int, v>{}, I7, nb0, nb1, fob, blk, pre, integral_constant<bool, has_epi>{});
+          else ktile(I0, integral_constant<int, v>{}, nb0, nb1, fob, blk, pre, integral_constant<bool, has_epi>{});
           fob = 0;
         });
         if constexpr (DIR == 2) pend = false;
@@ -609,7 +628,7 @@ void gemm_wide_kernel(GemmArgs g) {
         const int t0 = DIR == 2 ? 16 * nq + 16 : 0;
         for (int t = t0; t < ktb; ++t) {
           const bool more = t + 1 < ktb;
-          ktile(I0, I7, more ? dn0 : dg0, more ? dn1 : (DIR == 2 ? dg1 : dn1), fob, blk, nothing);
+          ktile(I0, I7, more ? dn0 : dg0, more ? dn1 : (DIR == 2 ? dg1 : dn1), fob, blk, nothing, std::false_type{});
           fob = 0;
         }
       }

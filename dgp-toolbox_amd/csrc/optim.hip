@@ -7,9 +7,13 @@ namespace dgp {
 
 __global__ void adam_kernel(double* __restrict__ params, const double* __restrict__ grad_elbo, double* __restrict__ m,
                             double* __restrict__ v, const ParamSeg* __restrict__ segs, int nseg, long total, double lr_t,
-                            double beta1, double beta2, double eps) {
+                            double beta1, double beta2, double eps, const double* __restrict__ t_dev) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
+  if (t_dev) {                         // Keras Adam: lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t), t from device memory
+    const double t = t_dev[0];
+    lr_t = lr_t * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t));
+  }
   int s = 0;
   while (s + 1 < nseg && idx >= segs[s + 1].off) ++s;
   const ParamSeg sg = segs[s];
@@ -43,9 +47,28 @@ __global__ void adam_kernel(double* __restrict__ params, const double* __restric
 
 hipError_t adam_apply(hipStream_t st, double* params, const double* grad_elbo, double* m, double* v,
                       const ParamSeg* segs_dev, int nseg, long total, double lr_t, double beta1, double beta2,
-                      double eps) {
+                      double eps, const double* t_dev) {
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, params, grad_elbo, m, v,
-                     segs_dev, nseg, total, lr_t, beta1, beta2, eps);
+                     segs_dev, nseg, total, lr_t, beta1, beta2, eps, t_dev);
+  return hipGetLastError();
+}
+
+__global__ void iter_bump_kernel(double* it, int seed_inc, int t_inc) {
+  uint64_t* seed = reinterpret_cast<uint64_t*>(it);
+  seed[0] += (uint64_t)seed_inc;
+  it[1] += (double)t_inc;
+}
+hipError_t iter_bump(hipStream_t st, double* it, int seed_inc, int t_inc) {
+  hipLaunchKernelGGL(iter_bump_kernel, dim3(1), dim3(1), 0, st, it, seed_inc, t_inc);
+  return hipGetLastError();
+}
+__global__ void iter_log_elbo_kernel(double* it, const double* scal, double* elbo_log, int cap) {
+  const int i = (int)it[2];
+  if (i >= 0 && i < cap) elbo_log[i] = scal[1];
+  it[2] = (double)(i + 1);
+}
+hipError_t iter_log_elbo(hipStream_t st, double* it, const double* scal, double* elbo_log, int cap) {
+  hipLaunchKernelGGL(iter_log_elbo_kernel, dim3(1), dim3(1), 0, st, it, scal, elbo_log, cap);
   return hipGetLastError();
 }
 

@@ -40,7 +40,8 @@ __device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t n, uint3
 
 __device__ __forceinline__ double draw_z(const ZSource& zs, int s, long n_local, int d, int D) {
   if (zs.zs) return zs.zs[((long)s * zs.Ntot + n_local) * D + d];
-  return philox_normal(zs.seed, (uint64_t)(zs.n_global0 + n_local), (uint32_t)s, (uint32_t)zs.layer, (uint32_t)d);
+  const uint64_t seed = zs.seed_dev ? *zs.seed_dev : zs.seed;
+  return philox_normal(seed, (uint64_t)(zs.n_global0 + n_local), (uint32_t)s, (uint32_t)zs.layer, (uint32_t)d);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {

@@ -23,7 +23,7 @@ SYMBOLS = [
     "dgp_propagate_vjp", "dgp_vjp_accumulate", "dgp_propagate_full_cov", "dgp_gpr_lml", "dgp_gpr_predict", "dgp_gpr_predict_vjp",
     "dgp_grad_partial", "dgp_acc_info", "dgp_acc_bind", "dgp_grad_finish", "dgp_grad_get", "dgp_last_elbo", "dgp_grad_step",
     "dgp_comm_unique_id", "dgp_comm_init", "dgp_comm_destroy", "dgp_comm_allreduce",
-    "dgp_adam_reset", "dgp_adam_step", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_dev_gemm",
+    "dgp_adam_reset", "dgp_adam_step", "dgp_adam_iterations", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_dev_gemm",
     "dgp_dev_chol", "dgp_dev_trinv", "dgp_dev_normals", "dgp_dev_mfma_peak",
 ]
 
@@ -98,6 +98,8 @@ def load():
         "dgp_adam_reset": (C.c_int, [vp]),
         "dgp_adam_step": (C.c_int, [vp, dbl, dbl, dbl, dbl, C.POINTER(C.c_uint8)]),
         "dgp_natgrad_step": (C.c_int, [vp, dbl, C.POINTER(C.c_uint8)]),
+        "dgp_adam_iterations": (C.c_int, [vp, i32, i32, u64, dbl, dbl, dbl, dbl, C.POINTER(C.c_uint8), dbl, C.POINTER(C.c_uint8),
+                                          i32, _dp]),
         "dgp_prof_enable": (C.c_int, [vp, i32]),
         "dgp_prof_read": (C.c_int, [vp, i32, _dp, C.POINTER(i64), _dp, _dp]),
         "dgp_dev_gemm": (C.c_int, [vp, i32, i64, i64, i64, _dp, i64, _dp, i64, _dp, i64, dbl, i32, i32, i32, i64, i32, _dp]),
@@ -371,6 +373,18 @@ class Context:
     def adam_step(self, lr, beta_1, beta_2, epsilon, trainable):
         t = (C.c_uint8 * len(trainable))(*[1 if x else 0 for x in trainable])
         self._chk(self._lib.dgp_adam_step(self._h, lr, beta_1, beta_2, epsilon, t))
+
+    def adam_iterations(self, n_iter, S, seed0, lr, beta_1, beta_2, epsilon, trainable, gamma=0.0, layer_mask=None,
+                        use_graph=-1, want_elbo=True):
+        """n_iter loop bodies of optimize_adam (gamma == 0) or of part 2 of optimize_nat_adam (gamma > 0) in one call
+        (dgp_adam_iterations; launch-bound models replay a captured hipGraph).  Returns the ELBOs the iterations would
+        print (or None)."""
+        t = (C.c_uint8 * len(trainable))(*[1 if x else 0 for x in trainable])
+        m = (C.c_uint8 * len(layer_mask))(*[1 if x else 0 for x in layer_mask]) if layer_mask is not None else None
+        out = np.empty(int(n_iter)) if want_elbo else None
+        self._chk(self._lib.dgp_adam_iterations(self._h, int(n_iter), int(S), int(seed0) & (2 ** 64 - 1), lr, beta_1, beta_2,
+                                                epsilon, t, float(gamma), m, int(use_graph), _ptr(out) if want_elbo else None))
+        return out
 
     def natgrad_step(self, gamma, layer_mask):
         t = (C.c_uint8 * len(layer_mask))(*[1 if x else 0 for x in layer_mask])

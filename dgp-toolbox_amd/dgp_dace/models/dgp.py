@@ -270,6 +270,29 @@ class DGP_Base:
 
     def _adam_loop(self, data, iterations, lr, beta_1, beta_2, epsilon, messages, natgrad=None):
         ctx = self._sync_model()
+        if self.minibatch_size is None and (self._dist is None or getattr(self, "_native_comm", False)):
+            # the loop bodies run inside the library, many per call (small models: one captured hipGraph per iteration);
+            # the printed lines are the same, they appear when a batch of iterations returns
+            self._sync_data(data)
+            self._select_batch(ctx, True)
+            gamma, mask = natgrad if natgrad is not None else (0.0, None)
+            per = 2 if natgrad is not None else 1
+            flags = self._trainable_flags()
+            step = 0
+            while step < iterations:
+                n = min(iterations - step, max(64, int(messages)) if messages else 4096)
+                seed0 = self.seed + self._eval_count
+                elbos = ctx.adam_iterations(n, self.num_samples, seed0, lr, beta_1, beta_2, epsilon, flags, gamma, mask,
+                                            want_elbo=bool(messages))
+                self._eval_count += per * n
+                self.last_seed = seed0 + per * n - 1
+                self._device_newer = True
+                if messages:
+                    for i in range(n):
+                        if (step + i) % messages == 0:
+                            self._say(f"ELBO: {elbos[i]}")
+                step += n
+            return
         for step in range(iterations):
             ctx = self._grad_step(data)
             ctx.adam_step(lr, beta_1, beta_2, epsilon, self._trainable_flags())

@@ -183,6 +183,17 @@ int dgp_comm_allreduce(dgp_ctx* ctx, void* device_ptr, int64_t n_doubles);
  * (gpflow.set_trainable, dgp.py:316-322).  Uses the gradient of the last dgp_grad_finish.          */
 int dgp_adam_reset(dgp_ctx* ctx);
 int dgp_adam_step(dgp_ctx* ctx, double lr, double beta_1, double beta_2, double epsilon, const uint8_t* trainable);
+/* n_iter loop bodies of DGP.optimize_adam (dgp.py:271-276: ELBO + gradient with fresh normals, Adam step) or, with
+ * gamma > 0, of part 2 of DGP.optimize_nat_adam (dgp.py:326-345: that, then a second evaluation and the natural-gradient
+ * step on the layers of layer_mask) in ONE call.  Evaluation k of the call draws its normals with seed0 + k (one
+ * evaluation per iteration, two with gamma > 0).  elbo_out (host, [n_iter], may be NULL): the ELBO each iteration would
+ * print.  use_graph = 1: one captured hipGraph is replayed per iteration (seed and Adam step count then live in device
+ * memory); 0: call by call; -1: the library decides (today: call by call -- the replay measured slower on launch-bound
+ * models, see the implementation).
+ * Results are those of the call-by-call sequence dgp_grad_step / dgp_adam_step (/ dgp_grad_step / dgp_natgrad_step).   */
+int dgp_adam_iterations(dgp_ctx* ctx, int32_t n_iter, int32_t S, uint64_t seed0, double lr, double beta_1, double beta_2,
+                        double epsilon, const uint8_t* trainable, double gamma, const uint8_t* layer_mask,
+                        int32_t use_graph, double* elbo_out);
 /* gpflow.optimizers.NaturalGradient(gamma).minimize on the (q_mu, q_sqrt) pairs of the layers with
  * layer_mask[l] != 0 (dgp.py:312-322,343).  Uses the gradient of the last dgp_grad_finish.         */
 int dgp_natgrad_step(dgp_ctx* ctx, double gamma, const uint8_t* layer_mask);

@@ -233,6 +233,57 @@ def test_grad_step_equals_partial_reduce_finish():
         ctx.grad_step(int(g["S"]) + 1, 0, zs)                  # wrong sample count
 
 
+@pytest.mark.parametrize("natgrad", [False, True])
+def test_adam_iterations_graph_replay_matches_call_by_call(natgrad):
+    """dgp_adam_iterations: n loop bodies of optimize_adam / optimize_nat_adam part 2 in one call.  The captured-hipGraph
+    replay (launch-bound models: seed and Adam step count live in device memory) must give the ELBOs and parameters of
+    the call-by-call sequence grad_step / adam_step (/ grad_step / natgrad_step) with the same seeds."""
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    X, Y, Z = notebook_data()
+    n, S = 9, 10
+    res = []
+    for mode in ("calls", "eager", "graph"):
+        m = DGP(X, Y, Z, [RBF(1.0, [1.0]) for _ in range(3)], [1, 1], Gaussian(), num_samples=S, seed=3)
+        for l in m.layers[:-1]:
+            l.q_sqrt.assign(l.q_sqrt * 1e-2)
+        mask = m._natgrad_setup(True) if natgrad else None
+        ctx = m._sync_model()
+        m._sync_data(m.data)
+        ctx.adam_reset()
+        flags = m._trainable_flags()
+        if mode == "calls":
+            el = []
+            for i in range(n):
+                per = 2 if natgrad else 1
+                ctx.grad_step(S, 100 + per * i, None)
+                ctx.adam_step(0.01, 0.9, 0.999, 1e-7, flags)
+                el.append(ctx.last_elbo())
+                if natgrad:
+                    ctx.grad_step(S, 100 + per * i + 1, None)
+                    ctx.natgrad_step(0.01, mask)
+            el = np.array(el)
+        else:
+            el = ctx.adam_iterations(n, S, 100, 0.01, 0.9, 0.999, 1e-7, flags, 0.01 if natgrad else 0.0, mask,
+                                     use_graph=1 if mode == "graph" else 0)
+        res.append((el, ctx.params_get()))
+    # (the split-K atomics make two runs of the SAME sequence differ in the last bits, and Adam's epsilon amplifies that
+    #  on this model, see test_nglast_trajectory_tolerance_is_amplified_rounding_noise: 1e-6 here; a wrong seed or step
+    #  count would show at 1e-2)
+    for el, th in res[1:]:
+        np.testing.assert_allclose(el, res[0][0], rtol=1e-6)
+        np.testing.assert_allclose(th, res[0][1], rtol=1e-5, atol=1e-7)
+    # a second call on the graph model reuses the instantiated graph and continues the seed / step sequence
+    m2 = DGP(X, Y, Z, [RBF(1.0, [1.0]) for _ in range(3)], [1, 1], Gaussian(), num_samples=S, seed=3)
+    ctx = m2._sync_model(); m2._sync_data(m2.data); ctx.adam_reset()
+    a = ctx.adam_iterations(5, S, 100, 0.01, 0.9, 0.999, 1e-7, m2._trainable_flags(), use_graph=1)
+    b = ctx.adam_iterations(4, S, 105, 0.01, 0.9, 0.999, 1e-7, m2._trainable_flags(), use_graph=1)
+    m3 = DGP(X, Y, Z, [RBF(1.0, [1.0]) for _ in range(3)], [1, 1], Gaussian(), num_samples=S, seed=3)
+    ctx3 = m3._sync_model(); m3._sync_data(m3.data); ctx3.adam_reset()
+    c = ctx3.adam_iterations(9, S, 100, 0.01, 0.9, 0.999, 1e-7, m3._trainable_flags(), use_graph=0)
+    np.testing.assert_allclose(np.concatenate([a, b]), c, rtol=1e-6)
+
+
 def test_chunking_and_philox_are_neutral():
     """Small workspace => many chunks: same ELBO and gradient as one chunk (Philox keyed by global index)."""
     g = load("case_B_nonwhite")
