@@ -133,7 +133,7 @@ int main(int argc, char** argv) {
           a.tri = TRI_B_LOWER; a.triblk = Mp; a.emul = Kt;
           c.a = a; c.c_elems = (size_t)Pm * Mp; c.rs_elems = 0; c.alg_flops = tri1; cases.push_back(c);
         }
-        if (!timing) {  // dense product (no hint)
+        if (!timing || getenv("WB_DENSE")) {  // dense product (no hint)
           Case c; c.name = "dense NN K=D*Mp";
           GemmArgs a; a.A = Tt; a.B = Scat; a.lda = DM; a.ldb = Mp; a.ldc = Mp; a.M = Pm; a.N = Mp; a.K = DM;
           a.sA = a.sB = a.sC = 0; a.batch = 1; a.splits = 1; a.ksplit = 0; a.alpha = 1.0; a.beta = 0; a.tri = TRI_NONE; a.triblk = 0;
