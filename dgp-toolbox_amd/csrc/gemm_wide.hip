@@ -18,10 +18,16 @@ bool gemm_wide_ok(const GemmArgs& a) {
   if ((a.M / WBM) * (a.N / WBN) < min_tiles) return false;
   if (a.M <= 0 || a.M % WBM != 0 || a.N <= 0 || a.N % WBN != 0 || a.K <= 0 || a.K % WBK != 0) return false;
   if (a.batch > 1 || a.splits > 1 || a.beta != 0) return false;
-  // second output C2 = C .* emul (dK -> g): the interleaved form (mode 2) has to load emul inside the k-tile stream, and on
-  // gfx9 waiting for that load also waits for the DMA requests issued just before it (vmcnt is in order): measured 2.7 ms
-  // against 2.1 ms on the 128 x 64 engine at 10^6 rows -> that product stays there
-  if (a.C2 != nullptr || a.emul != nullptr) return false;
+  // second output C2 = C .* emul (dK -> g): only as the interleaved mode 2 (B lower, one k block, plain epilogue), and off by
+  // default: that product moves 8 GB per 10^6 rows (A, emul in; C, C2 out) for 0.13 TFLOP, i.e. it is HBM-bound, and the
+  // 128 x 64 engine with two workgroups per CU streams it faster (2.06 ms against 2.20 ms; DGP_WIDE_EM2=1 selects mode 2)
+  if (a.C2 != nullptr || a.emul != nullptr) {
+    static int em2 = -1;
+    if (em2 < 0) { const char* e = getenv("DGP_WIDE_EM2"); em2 = e ? atoi(e) : 0; }
+    if (!em2 || a.tri != TRI_B_LOWER || a.K != a.triblk || a.alpha != 1.0 || a.rank != 0 || a.eadd != nullptr || a.epi != 0 ||
+        a.c_blocked || a.ascale_mode != 0 || a.C2 == nullptr || a.emul == nullptr)
+      return false;
+  }
   if (a.tri != TRI_NONE && a.tri != TRI_B_UPPER && a.tri != TRI_B_LOWER) return false;
   long kblen = a.K;
   if (a.tri != TRI_NONE) {
@@ -72,6 +78,7 @@ hipError_t gemm_wide(hipStream_t st, const GemmArgs& a) {
   int em = 0;
   const bool plain = dir != 0 && !sc && a.alpha == 1.0 && a.rank == 0 && a.eadd == nullptr && a.K == a.triblk;
   if (plain && a.epi == 2 && a.C2 == nullptr) em = 1;
+  else if (plain && a.epi == 0 && a.C2 != nullptr && dir == 2) em = 2;
   else if (plain && a.epi == 1) em = 3;
 #define W_LAUNCH(D, S, E) hipLaunchKernelGGL((gemm_wide_kernel<D, S, E>), dim3(grid), dim3(512), 0, st, a)
   if (sc) W_LAUNCH(1, true, 0);
@@ -81,6 +88,7 @@ hipError_t gemm_wide(hipStream_t st, const GemmArgs& a) {
     else W_LAUNCH(1, false, 0);
   } else {
     if (em == 1) W_LAUNCH(2, false, 1);
+    else if (em == 2) W_LAUNCH(2, false, 2);
     else if (em == 3) W_LAUNCH(2, false, 3);
     else W_LAUNCH(2, false, 0);
   }
