@@ -1,6 +1,7 @@
 // Host-side dispatch of the fp64 MFMA GEMM engine (see gemm_f64.h).
 #include "gemm_f64.h"
 #include "gemm_wide.h"
+#include "gemm_gram.h"
 #include <cstdlib>
 #include <algorithm>
 
@@ -166,6 +167,8 @@ hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args) {
   if (a.batch < 1) a.batch = 1;
   // row-panel products with a (block-)triangular or dense Mp-wide B: the wide-tile kernel
   if (op == GEMM_NN && !a.no_wide && gemm_wide_ok(a)) return gemm_wide(st, a);
+  // weighted Gram products over the points (lower triangle, Mp = 256): the single-staging kernel of gemm_gram.h
+  if (op == GEMM_TN && !a.no_wide && gemm_gram_ok(a)) return gemm_gram(st, a);
   switch (op) {
     case GEMM_NN: return dispatch<false, false>(st, a);
     case GEMM_NT: return dispatch<false, true>(st, a);

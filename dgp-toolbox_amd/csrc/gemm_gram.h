@@ -1,0 +1,317 @@
+// Weighted Gram kernel: G_d += sum_p s[p][d] c_p c_p^T for d = 0..D-1, lower triangle, Mp = 256.
+//   reference: what tf.GradientTape derives for d ELBO / d q_sqrt through  reduce_sum(A_tiled * (SK @ A_tiled))
+//   (layers.py:254-263): G_d = sum_p vbar_pd c_p c_p^T, W-bar_d = 2 G_d W_d  (SURVEY App. C step 2).
+// Why a kernel of its own next to the 128 x 64 engine's TN product (gemm_f64.h): that one computes the lower triangle at
+// 128 x 64 tile granularity (62.5 % of the dense product for a need of 50.2 %), stages the SAME k-tile of Ct twice (as A
+// and as B) and splits K into many chunks whose partial tiles are added with atomics.  Here:
+//   * one workgroup (8 waves) owns the whole 256 x 256 lower triangle of ONE d at a time and a contiguous range of the
+//     points.  The 136 lower 16 x 16 blocks are dealt 17 to a wave (53.1 % of dense, the same MFMA count in every wave)
+//     by a compile-time map (GramMap): the six off-diagonal 64 x 64 super-blocks go to six waves, each with one block
+//     borrowed from a diagonal super-block that shares a fragment with it; the two other waves own two (reduced)
+//     diagonal super-blocks each.  A wave therefore reads 4..8 B fragments and 4..8 A fragments per 68 MFMAs.  The maps
+//     differ per wave, so each wave runs its own specialisation (template W) of the k-loop, selected once per launch by
+//     a switch on the wave index; the hot loop of a wave is one k-tile (272 MFMAs, < 4 KB of code);
+//   * one k-tile of Ct (16 points x 256 columns, 32 KB) is staged ONCE by LDS-DMA and serves as both operands: B fragments
+//     as in gemm_wide.h, A fragments (c_p^T: row = column of Ct) by 8-byte reads of the same image; the weights s[p][d] of
+//     the k-tile's points travel with it (16 x D doubles) and scale the A fragments;
+//   * a ring of four stages, DMA three k-tiles ahead, counted vmcnt + raw s_barrier (gemm_wide.h's scheme); every workgroup
+//     walks ITS range of points once per d and adds its partial triangle with atomics D times per launch (72 MB in all
+//     for D = 8 on 256 workgroups, against 2 GB for 4096-point chunks).
+// Lane maps of v_mfma_f64_4x4x4_4b_f64: gemm_f64.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "gemm_wide.h"
+
+namespace dgp {
+
+constexpr int GR_STAGE_B = 16 * 256 * 8;        // 32 KB: [16 k][128 chunks of 16 B], chunk ^ ((k >> 1) & 1)
+constexpr int GR_STAGE_S = 2048;                // 16 points x up to 16 weights
+constexpr int GR_STAGE = GR_STAGE_B + GR_STAGE_S;
+constexpr int GR_NSTAGE = 4;
+
+struct GramArgs {
+  const double* C;      // [P][256] point-major (Ct)
+  const double* s;      // [P][D] weights (vbar), or nullptr = 1
+  double* G;            // [D][256][256], lower triangles accumulated with atomics (pre-initialised by the caller)
+  long P;               // points, a multiple of 16
+  int D;                // 1..16
+};
+
+// A wave's 17 blocks, in one or two GROUPS: group q has row blocks rows[q][0..nr[q]) and column blocks
+// cols[q][0..nc[q]); bit ri of mask[q][ci] says whether block (rows[q][ri], cols[q][ci]) belongs to the wave.  The A
+// fragments (one per row block) are loaded group by group, one group ahead of their use.
+struct GramMap {
+  int ng;
+  int nr[2], nc[2];
+  int rows[2][5], cols[2][5];
+  unsigned mask[2][5];
+};
+
+constexpr GramMap gram_map(int w) {
+  GramMap m{};
+  if (w < 2) {
+    // two diagonal 64 x 64 super-blocks, (2w, 2w) and (2w+1, 2w+1), lower parts, minus the blocks lent to other waves
+    m.ng = 2;
+    for (int q = 0; q < 2; ++q) {
+      m.nr[q] = 4; m.nc[q] = 4;
+      for (int i = 0; i < 4; ++i) { m.rows[q][i] = 8 * w + 4 * q + i; m.cols[q][i] = 8 * w + 4 * q + i; m.mask[q][i] = 0xfu & ~((1u << i) - 1); }
+    }
+    if (w == 0) { m.mask[0][0] &= ~8u; m.mask[0][1] &= ~8u; m.mask[0][2] &= ~8u; }     // (3,0) (3,1) (3,2)
+    else { m.mask[0][0] &= ~8u; m.mask[1][0] &= ~8u; m.mask[1][1] &= ~8u; }            // (11,8) (15,12) (15,13)
+    return m;
+  }
+  // off-diagonal super-block (I, J) + one borrowed block
+  const int SI[6] = {1, 2, 3, 2, 3, 3}, SJ[6] = {0, 0, 0, 1, 1, 2};
+  const int I = SI[w - 2], J = SJ[w - 2];
+  m.ng = 1;
+  for (int i = 0; i < 4; ++i) { m.rows[0][i] = 4 * I + i; m.cols[0][i] = 4 * J + i; m.mask[0][i] = 0xf; }
+  if (w <= 4) {            // borrowed (3, w - 2): a fifth row, in a column the wave already reads: a group of its own
+    m.ng = 2;              // (first, so that the k-tile does not end with it), which keeps the fragment set at four rows
+    m.nr[1] = 4; m.nc[1] = 4;
+    for (int i = 0; i < 4; ++i) { m.rows[1][i] = m.rows[0][i]; m.cols[1][i] = m.cols[0][i]; m.mask[1][i] = 0xf; }
+    m.nr[0] = 1; m.nc[0] = 1;
+    m.rows[0][0] = 3; m.cols[0][0] = w - 2; m.mask[0][0] = 1u;
+  } else {                 // borrowed (11, 8), (15, 12), (15, 13): a fifth column (read FIRST: the short unit is not the
+    m.nr[0] = 4; m.nc[0] = 5;     // one the k-tile ends with), in the wave's last row
+    for (int i = 4; i > 0; --i) { m.cols[0][i] = m.cols[0][i - 1]; m.mask[0][i] = m.mask[0][i - 1]; }
+    m.cols[0][0] = w == 5 ? 8 : (w == 6 ? 12 : 13);
+    m.mask[0][0] = 1u << 3;
+  }
+  return m;
+}
+
+constexpr int gr_popc(unsigned x) { int n = 0; while (x) { n += x & 1; x >>= 1; } return n; }
+constexpr int gram_units(const GramMap& m) { return m.nc[0] + (m.ng > 1 ? m.nc[1] : 0); }       // per k-substep
+constexpr int gram_blk(const GramMap& m, int q, int ci, int ri) {      // index of a block among the wave's 17
+  int n = 0;
+  for (int qq = 0; qq < m.ng; ++qq)
+    for (int c = 0; c < m.nc[qq]; ++c) {
+      if (qq == q && c == ci) return n + gr_popc(m.mask[qq][c] & ((1u << ri) - 1));
+      n += gr_popc(m.mask[qq][c]);
+    }
+  return n;
+}
+constexpr int gram_nblk(const GramMap& m) { return gram_blk(m, m.ng, 0, 0); }
+
+template <int W> struct GramMapOf { static constexpr GramMap m = gram_map(W); };
+
+template <int W, bool SC>
+__device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wave, int lane) {
+  using GM = GramMapOf<W>;
+  constexpr int NG = GM::m.ng, NS = gram_units(GM::m);
+  constexpr int NRM = GM::m.nr[0] > GM::m.nr[NG - 1] ? GM::m.nr[0] : GM::m.nr[NG - 1];
+  constexpr int NB = gram_nblk(GM::m);
+  static_assert(NB == 17, "every wave owns 17 blocks");
+  constexpr int U = 4 * NS;                       // units per k-tile: (substep, group, column index)
+  static_assert(U % 4 == 0 && GM::m.nc[NG - 1] >= 2, "slot ring / barrier placement");
+  const int li = lane & 15, lk = lane >> 4;
+  const int sw = lk & 1;
+  // (all fragment addresses include the current stage: they are advanced at every k-tile barrier)
+  // B fragment of column block c, substep (s8, q): k = 8 s8 + 2 lk + q, 32 contiguous bytes at columns 16 c + 4 (li & 3),
+  // the two 16-byte halves swapped when (k >> 1) & 1 = lk & 1
+  unsigned bB0 = (unsigned)((2 * lk) * 2048 + (li & 3) * 32 + sw * 16), bB1 = (unsigned)((2 * lk) * 2048 + (li & 3) * 32 + (1 - sw) * 16);
+  // A fragment of row block r: element (k, m = 16 r + li) of the same image: chunk m / 2, swizzled, + (m & 1) * 8.
+  // Within a group the row blocks are consecutive (+ possibly one stray): one address per group and stray
+  unsigned bA[NG][5];
+#pragma unroll
+  for (int q = 0; q < NG; ++q)
+#pragma unroll
+    for (int ri = 0; ri < GM::m.nr[q]; ++ri) {
+      const int m = GM::m.rows[q][ri] * 16 + li;
+      bA[q][ri] = (unsigned)((2 * lk) * 2048 + (((m >> 1) ^ sw) << 4) + (m & 1) * 8);
+    }
+
+  const long KT = g.P / 16;
+  const long kt_lo = (KT * blockIdx.x) / gridDim.x, kt_hi = (KT * (blockIdx.x + 1)) / gridDim.x;
+  const int nkt = (int)(kt_hi - kt_lo);
+  if (nkt <= 0) return;                            // (every wave of the workgroup returns: same range)
+
+  const bool two = g.D > 8;
+  const bool extra = SC && (W == 0 || (W == 1 && two));      // this wave also requests a piece of the weights
+  // DMA: the B image = 32 pieces of 1 KB (half a k row each): wave w issues pieces 4 w .. 4 w + 3 (k rows 2 w, 2 w + 1);
+  // the weights (16 x D doubles, contiguous) = 1 piece (D <= 8) or 2 (D <= 16), requested by wave 0 / waves 0 and 1
+  const unsigned offB = (unsigned)((lane ^ (wave & 1)) * 16);
+  auto issue = [&](long kt, int stage) __attribute__((always_inline)) {
+    const double* ub = g.C + (kt * 16 + wave * 2) * 256;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(ub), 0, 0x7ffffff0, 0x00020000);
+    char* base = smem + stage * GR_STAGE;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, W_LDS3(base + (wave * 4 + p) * 1024), 16, offB, (p >> 1) * 2048 + (p & 1) * 1024, 0, 0);
+    if constexpr (SC && W <= 1) {
+      if (extra) {
+        // rows 16 kt .. 16 kt + 15 of s: 16 D doubles from s + 16 kt D; reads past the end of s return zeros (num_records)
+        const long off = kt * 16 * g.D * 8 + W * 1024, left = g.P * g.D * 8 - off;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(g.s) + off), 0, (int)(left > 0x7ffffff0 ? 0x7ffffff0 : (left > 0 ? left : 0)), 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, W_LDS3(base + GR_STAGE_B + W * 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
+      }
+    }
+  };
+  // wait until at most two / three of this wave's k-tile requests are outstanding (4 or 5 DMA instructions each)
+  auto wait_tiles2 = [&]() __attribute__((always_inline)) {
+    if (extra) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  };
+  auto wait_tiles3 = [&]() __attribute__((always_inline)) {
+    if (extra) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  };
+  auto kt_of = [&](int i) { return kt_lo + (i < nkt ? i : nkt - 1); };   // requests past the range re-read its last k-tile
+
+  double acc[NB][4];
+  double fb[4][4];              // ring of four units: [slot][e]
+  double fr[NRM], fa[NRM];      // A fragments of a group: raw (read one phase ahead) and scaled
+  double fw = 1.0;
+
+  auto readB = [&](int slot, unsigned off) __attribute__((always_inline)) {
+    const d2_t v0 = *reinterpret_cast<const d2_t*>(smem + bB0 + off);
+    const d2_t v1 = *reinterpret_cast<const d2_t*>(smem + bB1 + off);
+    fb[slot][0] = v0[0]; fb[slot][1] = v0[1]; fb[slot][2] = v1[0]; fb[slot][3] = v1[1];
+  };
+  // unit u of a k-tile -> substep, group, column index
+  auto u_sub = [](int u) constexpr { return u / NS; };
+  auto u_grp = [](int u) constexpr { return (u % NS) < GM::m.nc[0] ? 0 : 1; };
+  auto u_ci = [](int u) constexpr { return (u % NS) < GM::m.nc[0] ? (u % NS) : (u % NS) - GM::m.nc[0]; };
+  auto uoff = [&](int u) constexpr {
+    const int sub = u_sub(u);
+    return (unsigned)((8 * (sub >> 1) + (sub & 1)) * 2048 + GM::m.cols[u_grp(u)][u_ci(u)] * 128);
+  };
+
+  for (int d = 0; d < g.D; ++d) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[b][e] = 0.0;
+    unsigned wbase = (unsigned)(GR_STAGE_B + (2 * lk * g.D + d) * 8);
+    const unsigned wstep = (unsigned)(g.D * 8);
+    // raw A fragments (and the weight) of phase ph = substep * NG + group
+    auto rawA = [&](auto phc) __attribute__((always_inline)) {
+      constexpr int ph = decltype(phc)::value, sub = ph / NG, q = ph % NG;
+      constexpr unsigned ko = (unsigned)((8 * (sub >> 1) + (sub & 1)) * 2048);
+#pragma unroll
+      for (int ri = 0; ri < GM::m.nr[q]; ++ri) fr[ri] = *reinterpret_cast<const double*>(smem + bA[q][ri] + ko);
+      if constexpr (SC) fw = *reinterpret_cast<const double*>(smem + wbase + (unsigned)(8 * (sub >> 1) + (sub & 1)) * wstep);
+    };
+
+    // ---- prologue: four k-tiles requested, the first one landed and published
+    issue(kt_of(0), 0);
+    issue(kt_of(1), 1);
+    issue(kt_of(2), 2);
+    issue(kt_of(3), 3);
+    wait_tiles3();
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    rawA(std::integral_constant<int, 0>{});
+    readB(0, uoff(0));
+    readB(1, uoff(1));
+
+    for (int i = 0; i < nkt; ++i) {
+      // unit u = (substep, group, column index): its B fragment sits in slot u & 3 and was read two units earlier
+      w_static_for<0, U>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, sub = u_sub(u), q = u_grp(u), ci = u_ci(u), ph = sub * NG + q;
+        constexpr bool ph_start = ci == 0;
+        if constexpr (ph_start) {
+#pragma unroll
+          for (int ri = 0; ri < GM::m.nr[q]; ++ri) fa[ri] = SC ? fr[ri] * fw : fr[ri];
+          if constexpr (ph + 1 < 4 * NG) rawA(std::integral_constant<int, ph + 1>{});
+        }
+        if constexpr (u == U - 2) {
+          // every LDS read of this stage has been issued (units U-2, U-1 were read ahead): wait for them and for this
+          // wave's pieces of the NEXT k-tile (the two after it may stay in flight); the barrier then publishes the next
+          // k-tile and releases this stage, into which the k-tile four ahead is requested
+          __builtin_amdgcn_sched_barrier(0);
+          wait_tiles2();
+          __builtin_amdgcn_s_barrier();
+          {
+            const int dstep = stage == GR_NSTAGE - 1 ? -(GR_NSTAGE - 1) * GR_STAGE : GR_STAGE;
+#pragma unroll
+            for (int qq = 0; qq < NG; ++qq)
+#pragma unroll
+              for (int ri = 0; ri < GM::m.nr[qq]; ++ri) bA[qq][ri] += dstep;
+            bB0 += dstep; bB1 += dstep; wbase += dstep;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          issue(kt_of(i + 4), stage);
+          rawA(std::integral_constant<int, 0>{});
+        }
+        readB((u + 2) & 3, uoff((u + 2) % U));
+        w_static_for<0, GM::m.nr[q]>([&](auto rc) __attribute__((always_inline)) {
+          constexpr int ri = decltype(rc)::value;
+          if constexpr ((GM::m.mask[q][ci] >> ri) & 1u) {
+            constexpr int b = gram_blk(GM::m, q, ci, ri);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[b][e] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[ri], fb[u & 3][e], acc[b][e], 0, 0, 0);
+          }
+        });
+        // issue order inside the unit: its first MFMA (it carries the wait for the fragments), then one LDS read per MFMA
+        constexpr int nm = 4 * gr_popc(GM::m.mask[q][ci]);
+        if constexpr (u == U - 2) {
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          constexpr int n_ds = 2 + ((ph_start && ph + 1 < 4 * NG) ? GM::m.nr[(ph + 1) % NG] + (SC ? 1 : 0) : 0);
+          constexpr int n_il = n_ds < nm - 1 ? n_ds : nm - 1;
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          w_static_for<0, n_il>([&](auto) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          });
+          if constexpr (n_ds > n_il) __builtin_amdgcn_sched_group_barrier(0x100, n_ds - n_il, 0);
+          if constexpr (nm - 1 - n_il > 0) __builtin_amdgcn_sched_group_barrier(0x008, nm - 1 - n_il, 0);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      stage = (stage + 1) & (GR_NSTAGE - 1);
+    }
+    // ---- flush: this workgroup's partial lower triangle of G_d.  acc[b][e] of lane (li, lk) is
+    //      G[16 r + 4 (li >> 2) + lk][16 c + 4 (li & 3) + e]
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // (the requests past the range)
+    __builtin_amdgcn_s_barrier();
+    {
+      const int back = stage * GR_STAGE;       // the next d starts in stage 0 again
+#pragma unroll
+      for (int qq = 0; qq < NG; ++qq)
+#pragma unroll
+        for (int ri = 0; ri < GM::m.nr[qq]; ++ri) bA[qq][ri] -= back;
+      bB0 -= back; bB1 -= back;
+    }
+    double* __restrict__ Gd = g.G + (long)d * 256 * 256 + (long)(4 * (li >> 2) + lk) * 256 + 4 * (li & 3);
+    w_static_for<0, NS>([&](auto xc) __attribute__((always_inline)) {
+      constexpr int x = decltype(xc)::value, q = u_grp(x), ci = u_ci(x);
+      w_static_for<0, GM::m.nr[q]>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int ri = decltype(rc)::value;
+        if constexpr ((GM::m.mask[q][ci] >> ri) & 1u) {
+          constexpr int b = gram_blk(GM::m, q, ci, ri);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) unsafeAtomicAdd(Gd + (long)GM::m.rows[q][ri] * 16 * 256 + GM::m.cols[q][ci] * 16 + e, acc[b][e]);
+        }
+      });
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+template <bool SC>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_gram_kernel(GramArgs g) {
+  __shared__ __attribute__((aligned(1024))) char smem[GR_NSTAGE * GR_STAGE];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  switch (wave) {
+    case 0: gram_wave<0, SC>(g, smem, wave, lane); break;
+    case 1: gram_wave<1, SC>(g, smem, wave, lane); break;
+    case 2: gram_wave<2, SC>(g, smem, wave, lane); break;
+    case 3: gram_wave<3, SC>(g, smem, wave, lane); break;
+    case 4: gram_wave<4, SC>(g, smem, wave, lane); break;
+    case 5: gram_wave<5, SC>(g, smem, wave, lane); break;
+    case 6: gram_wave<6, SC>(g, smem, wave, lane); break;
+    default: gram_wave<7, SC>(g, smem, wave, lane); break;
+  }
+}
+
+bool gemm_gram_ok(const GemmArgs& a);                    // a TN product this kernel can take (gemm_wide.hip)
+hipError_t gemm_gram(hipStream_t st, const GemmArgs& a);
+
+}  // namespace dgp
