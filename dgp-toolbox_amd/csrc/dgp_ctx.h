@@ -85,6 +85,7 @@ struct dgp_ctx {
   long batch_lo = 0, batch_n = 0;   // window of the resident points the bound is evaluated on (batch_n == 0: all of them)
   double data_scale = 1.0;          // factor on the data term (N / batch size for a minibatch estimate)
   double *acc = nullptr, *acc_own = nullptr;
+  double *gram_ws = nullptr;                         // partial triangles of the weighted Gram kernel (layers with Mp = 256)
   long n_acc = 0;
   double* scal = nullptr;   // device scalars: [0] sum KL, [1] ELBO of last grad_finish, [2] scratch data term
   int* info = nullptr;
@@ -371,7 +372,7 @@ void free_model(dgp_ctx* ctx) {
   }
   ctx->L.clear();
   dev_free(ctx->params); dev_free(ctx->grad); dev_free(ctx->adam_m); dev_free(ctx->adam_v);
-  dev_free(ctx->segs_dev); dev_free(ctx->mean_params); dev_free(ctx->acc_own);
+  dev_free(ctx->segs_dev); dev_free(ctx->mean_params); dev_free(ctx->acc_own); dev_free(ctx->gram_ws);
   ctx->acc = nullptr;
   for (auto& set : ctx->smset) for (auto& s : set) dev_free(s);
   for (auto& z : ctx->zs_dev) dev_free(z);
@@ -681,6 +682,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       GemmArgs a = mk(Mp, Mp, Pl, y.Ct, Mp, y.Ct, Mp, acc + y.acc_G, Mp, 1.0, 1);
       a.batch = D; a.sC = MM; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp) * D, Pl, (long)Mp * 8);
       a.ascale = y.vbar; a.as_ld = D; a.ascale_mode = 2;
+      a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = ctx->gram_ws ? gemm_gram_ws_bytes() : 0;     // (Mp = 256: gemm_gram.h)
       RET(GX(ctx, 0, GEMM_TN, a, tri1 * D, (double)Pl * Mp * 8));
     }
     {

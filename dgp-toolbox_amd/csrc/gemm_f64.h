@@ -100,6 +100,8 @@ struct GemmArgs {
   // optional second output C2 = (alpha * A B) .* E  (same shape / leading dimension as C; used for g = dK .* K)
   const double* emul = nullptr;
   double* C2 = nullptr;
+  double* gram_ws = nullptr;   // scratch for gemm_gram.h's partial triangles (gram_ws_bytes >= gemm_gram_ws_bytes())
+  long gram_ws_bytes = 0;
   int no_wide = 0;     // 1: keep this product on the 128 x 64 engine even where the wide-tile kernel (gemm_wide.h) applies
 };
 
@@ -718,5 +720,9 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 // Host-side dispatcher (defined in gemm_f64.hip)
 enum GemmOp : int { GEMM_NN = 0, GEMM_NT = 1, GEMM_TN = 2 };
 hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args);
+// weighted Gram products over the points (gemm_gram.h / gemm_gram.hip)
+bool gemm_gram_ok(const GemmArgs& a);
+long gemm_gram_ws_bytes();
+hipError_t gemm_gram(hipStream_t st, const GemmArgs& a);
 
 }  // namespace dgp

@@ -1,7 +1,6 @@
 // Host-side dispatch of the fp64 MFMA GEMM engine (see gemm_f64.h).
 #include "gemm_f64.h"
 #include "gemm_wide.h"
-#include "gemm_gram.h"
 #include <cstdlib>
 #include <algorithm>
 

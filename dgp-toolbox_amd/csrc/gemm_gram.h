@@ -14,9 +14,15 @@
 //   * one k-tile of Ct (16 points x 256 columns, 32 KB) is staged ONCE by LDS-DMA and serves as both operands: B fragments
 //     as in gemm_wide.h, A fragments (c_p^T: row = column of Ct) by 8-byte reads of the same image; the weights s[p][d] of
 //     the k-tile's points travel with it (16 x D doubles) and scale the A fragments;
-//   * a ring of four stages, DMA three k-tiles ahead, counted vmcnt + raw s_barrier (gemm_wide.h's scheme); every workgroup
-//     walks ITS range of points once per d and adds its partial triangle with atomics D times per launch (72 MB in all
-//     for D = 8 on 256 workgroups, against 2 GB for 4096-point chunks).
+//   * a ring of four stages filled by LDS-DMA with counted vmcnt + raw s_barrier (gemm_wide.h's scheme), but ONE stage more
+//     than the requests in flight need: the barrier of k-tile i (publish k-tile i + 1, request k-tile i + 3 into the
+//     stage of k-tile i - 1) sits in the MIDDLE of k-tile i, needs no LDS read to be complete, and is surrounded by MFMA
+//     work whose fragments are already on their way - no drain and no burst of first reads behind it;
+//   * no atomics: the D * P / 16 k-tiles, d-major, are cut into one contiguous range per workgroup (at most two d each);
+//     a workgroup stores its one or two partial triangles (278 KB each, coalesced) and gram_reduce_kernel adds them to
+//     G_d in a fixed order - 71 MB of traffic per launch and a reproducible sum.  (Measured: 256 workgroups adding
+//     their triangles to the same G_d with fp64 atomics cost 0.23 ms per d, 1.9 of 9.3 ms at D = 8, and 2 GB of atomic
+//     traffic per launch for the 128 x 64 engine's 4096-point chunks.)
 // Lane maps of v_mfma_f64_4x4x4_4b_f64: gemm_f64.h.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -35,10 +41,18 @@ constexpr int GR_NSTAGE = 4;
 struct GramArgs {
   const double* C;      // [P][256] point-major (Ct)
   const double* s;      // [P][D] weights (vbar), or nullptr = 1
-  double* G;            // [D][256][256], lower triangles accumulated with atomics (pre-initialised by the caller)
+  double* G;            // [D][256][256]: the lower triangles are ADDED to it (by gram_reduce_kernel)
+  double* ws;           // partial triangles: [2 * gridDim.x slots][136 blocks][64 lanes][4]  (GR_SLOT_BYTES each)
   long P;               // points, a multiple of 16
   int D;                // 1..16
 };
+constexpr long GR_SLOT_DOUBLES = 136L * 256;
+constexpr long GR_SLOT_BYTES = GR_SLOT_DOUBLES * 8;
+// Work split: the D * KT k-tiles (KT = P / 16), d-major, are cut into gridDim.x equal contiguous ranges; workgroup b owns
+// [F b / G, F (b + 1) / G): at most TWO d (D <= G), i.e. at most two segments, each with its own partial triangle
+// (slot 2 b + segment).  Every workgroup therefore flushes once or twice per launch, whatever D.
+__host__ __device__ inline long gram_cut(long F, long b, long G) { return (F * b) / G; }
+
 
 // A wave's 17 blocks, in one or two GROUPS: group q has row blocks rows[q][0..nr[q]) and column blocks
 // cols[q][0..nc[q]); bit ri of mask[q][ci] says whether block (rows[q][ri], cols[q][ci]) belongs to the wave.  The A
@@ -106,6 +120,7 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
   constexpr int NB = gram_nblk(GM::m);
   static_assert(NB == 17, "every wave owns 17 blocks");
   constexpr int U = 4 * NS;                       // units per k-tile: (substep, group, column index)
+  constexpr int UB = 2 * NS;                      // the unit that carries the k-tile's barrier
   static_assert(U % 4 == 0 && GM::m.nc[NG - 1] >= 2, "slot ring / barrier placement");
   const int li = lane & 15, lk = lane >> 4;
   const int sw = lk & 1;
@@ -113,21 +128,14 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
   // B fragment of column block c, substep (s8, q): k = 8 s8 + 2 lk + q, 32 contiguous bytes at columns 16 c + 4 (li & 3),
   // the two 16-byte halves swapped when (k >> 1) & 1 = lk & 1
   unsigned bB0 = (unsigned)((2 * lk) * 2048 + (li & 3) * 32 + sw * 16), bB1 = (unsigned)((2 * lk) * 2048 + (li & 3) * 32 + (1 - sw) * 16);
-  // A fragment of row block r: element (k, m = 16 r + li) of the same image: chunk m / 2, swizzled, + (m & 1) * 8.
-  // Within a group the row blocks are consecutive (+ possibly one stray): one address per group and stray
-  unsigned bA[NG][5];
-#pragma unroll
-  for (int q = 0; q < NG; ++q)
-#pragma unroll
-    for (int ri = 0; ri < GM::m.nr[q]; ++ri) {
-      const int m = GM::m.rows[q][ri] * 16 + li;
-      bA[q][ri] = (unsigned)((2 * lk) * 2048 + (((m >> 1) ^ sw) << 4) + (m & 1) * 8);
-    }
+  // A fragment of row block r: element (k, m = 16 r + li) of the same image: chunk m / 2 = 8 r + (li >> 1), swizzled
+  // (bit 0 only), + (m & 1) * 8: ONE per-lane address, the row block is a compile-time offset of 128 r bytes
+  unsigned bA = (unsigned)((2 * lk) * 2048 + (((li >> 1) ^ sw) << 4) + (li & 1) * 8);
 
-  const long KT = g.P / 16;
-  const long kt_lo = (KT * blockIdx.x) / gridDim.x, kt_hi = (KT * (blockIdx.x + 1)) / gridDim.x;
-  const int nkt = (int)(kt_hi - kt_lo);
-  if (nkt <= 0) return;                            // (every wave of the workgroup returns: same range)
+  const long KT = g.P / 16, F = KT * g.D;
+  const long f_lo = gram_cut(F, blockIdx.x, gridDim.x), f_hi = gram_cut(F, blockIdx.x + 1, gridDim.x);
+  long kt_lo = 0;             // current segment: k-tiles [kt_lo, kt_lo + nkt) of output d
+  int nkt = 0;
 
   const bool two = g.D > 8;
   const bool extra = SC && (W == 0 || (W == 1 && two));      // this wave also requests a piece of the weights
@@ -151,12 +159,12 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
       }
     }
   };
-  // wait until at most two / three of this wave's k-tile requests are outstanding (4 or 5 DMA instructions each)
-  auto wait_tiles2 = [&]() __attribute__((always_inline)) {
-    if (extra) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  // wait until at most one / two of this wave's k-tile requests are outstanding (4 or 5 DMA instructions each)
+  auto wait_tiles1 = [&]() __attribute__((always_inline)) {
+    if (extra) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   };
-  auto wait_tiles3 = [&]() __attribute__((always_inline)) {
-    if (extra) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  auto wait_tiles2 = [&]() __attribute__((always_inline)) {
+    if (extra) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   };
   auto kt_of = [&](int i) { return kt_lo + (i < nkt ? i : nkt - 1); };   // requests past the range re-read its last k-tile
 
@@ -179,7 +187,11 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
     return (unsigned)((8 * (sub >> 1) + (sub & 1)) * 2048 + GM::m.cols[u_grp(u)][u_ci(u)] * 128);
   };
 
-  for (int d = 0; d < g.D; ++d) {
+  int seg = 0;
+  for (long f = f_lo; f < f_hi; f += nkt, ++seg) {
+    const int d = (int)(f / KT);
+    kt_lo = f - (long)d * KT;
+    nkt = (int)((KT - kt_lo) < (f_hi - f) ? (KT - kt_lo) : (f_hi - f));
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -191,16 +203,15 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
       constexpr int ph = decltype(phc)::value, sub = ph / NG, q = ph % NG;
       constexpr unsigned ko = (unsigned)((8 * (sub >> 1) + (sub & 1)) * 2048);
 #pragma unroll
-      for (int ri = 0; ri < GM::m.nr[q]; ++ri) fr[ri] = *reinterpret_cast<const double*>(smem + bA[q][ri] + ko);
+      for (int ri = 0; ri < GM::m.nr[q]; ++ri) fr[ri] = *reinterpret_cast<const double*>(smem + bA + (ko + GM::m.rows[q][ri] * 128));
       if constexpr (SC) fw = *reinterpret_cast<const double*>(smem + wbase + (unsigned)(8 * (sub >> 1) + (sub & 1)) * wstep);
     };
 
-    // ---- prologue: four k-tiles requested, the first one landed and published
+    // ---- prologue: three k-tiles requested, the first one landed and published
     issue(kt_of(0), 0);
     issue(kt_of(1), 1);
     issue(kt_of(2), 2);
-    issue(kt_of(3), 3);
-    wait_tiles3();
+    wait_tiles2();
     __builtin_amdgcn_s_barrier();
     int stage = 0;
     rawA(std::integral_constant<int, 0>{});
@@ -208,6 +219,7 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
     readB(1, uoff(1));
 
     for (int i = 0; i < nkt; ++i) {
+      const int dstep = stage == GR_NSTAGE - 1 ? -(GR_NSTAGE - 1) * GR_STAGE : GR_STAGE;
       // unit u = (substep, group, column index): its B fragment sits in slot u & 3 and was read two units earlier
       w_static_for<0, U>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value, sub = u_sub(u), q = u_grp(u), ci = u_ci(u), ph = sub * NG + q;
@@ -215,26 +227,36 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
         if constexpr (ph_start) {
 #pragma unroll
           for (int ri = 0; ri < GM::m.nr[q]; ++ri) fa[ri] = SC ? fr[ri] * fw : fr[ri];
-          if constexpr (ph + 1 < 4 * NG) rawA(std::integral_constant<int, ph + 1>{});
+          // raw fragments of the next phase; the k-tile's last phase reads those of the NEXT k-tile's first one (its
+          // stage was published by this k-tile's barrier)
+          if constexpr (ph + 1 < 4 * NG) {
+            rawA(std::integral_constant<int, ph + 1>{});
+          } else {
+            bA += dstep; wbase += dstep;
+            rawA(std::integral_constant<int, 0>{});
+          }
+          // (fence: left to itself the scheduler sinks these reads to the last LDS slots before their first use, which
+          //  for the k-tile's last phase is the top of the next iteration)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (u == UB) {
+          // mid k-tile: this wave's pieces of the NEXT k-tile have landed (the one after it may stay in flight); the
+          // barrier publishes the next k-tile and certifies that every wave has left the PREVIOUS k-tile, whose stage
+          // takes the request for the k-tile three ahead.  (No LDS read has to be complete here: the current stage is
+          // not overwritten before the next barrier.)
+          __builtin_amdgcn_sched_barrier(0);
+          wait_tiles1();
+#ifndef GR_ABL_NOBAR
+          __builtin_amdgcn_s_barrier();
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+#ifndef GR_ABL_NODMA
+          issue(kt_of(i + 3), (stage + 3) & (GR_NSTAGE - 1));
+#endif
         }
         if constexpr (u == U - 2) {
-          // every LDS read of this stage has been issued (units U-2, U-1 were read ahead): wait for them and for this
-          // wave's pieces of the NEXT k-tile (the two after it may stay in flight); the barrier then publishes the next
-          // k-tile and releases this stage, into which the k-tile four ahead is requested
-          __builtin_amdgcn_sched_barrier(0);
-          wait_tiles2();
-          __builtin_amdgcn_s_barrier();
-          {
-            const int dstep = stage == GR_NSTAGE - 1 ? -(GR_NSTAGE - 1) * GR_STAGE : GR_STAGE;
-#pragma unroll
-            for (int qq = 0; qq < NG; ++qq)
-#pragma unroll
-              for (int ri = 0; ri < GM::m.nr[qq]; ++ri) bA[qq][ri] += dstep;
-            bB0 += dstep; bB1 += dstep; wbase += dstep;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          issue(kt_of(i + 4), stage);
-          rawA(std::integral_constant<int, 0>{});
+          // from here on the B fragment reads belong to the next k-tile
+          bB0 += dstep; bB1 += dstep;
         }
         readB((u + 2) & 3, uoff((u + 2) % U));
         w_static_for<0, GM::m.nr[q]>([&](auto rc) __attribute__((always_inline)) {
@@ -247,44 +269,46 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
         });
         // issue order inside the unit: its first MFMA (it carries the wait for the fragments), then one LDS read per MFMA
         constexpr int nm = 4 * gr_popc(GM::m.mask[q][ci]);
-        if constexpr (u == U - 2) {
-          __builtin_amdgcn_sched_barrier(0);
-        } else {
-          constexpr int n_ds = 2 + ((ph_start && ph + 1 < 4 * NG) ? GM::m.nr[(ph + 1) % NG] + (SC ? 1 : 0) : 0);
-          constexpr int n_il = n_ds < nm - 1 ? n_ds : nm - 1;
+        {
+          constexpr int n_ds = 2;
+          constexpr int n_vm = u == UB ? 4 : 0;                 // (the fifth request of waves 0 / 1 floats)
+          constexpr int n_il = n_ds + n_vm < nm - 1 ? n_ds + n_vm : nm - 1;
+          constexpr int n_il_vm = n_vm < n_il ? n_vm : n_il, n_il_ds = n_il - n_il_vm;
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          w_static_for<0, n_il>([&](auto) __attribute__((always_inline)) {
+          w_static_for<0, n_il_vm>([&](auto) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          });
+          w_static_for<0, n_il_ds>([&](auto) __attribute__((always_inline)) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           });
-          if constexpr (n_ds > n_il) __builtin_amdgcn_sched_group_barrier(0x100, n_ds - n_il, 0);
+          if constexpr (n_vm > n_il_vm) __builtin_amdgcn_sched_group_barrier(0x020, n_vm - n_il_vm, 0);
+          if constexpr (n_ds > n_il_ds) __builtin_amdgcn_sched_group_barrier(0x100, n_ds - n_il_ds, 0);
           if constexpr (nm - 1 - n_il > 0) __builtin_amdgcn_sched_group_barrier(0x008, nm - 1 - n_il, 0);
         }
       });
       __builtin_amdgcn_sched_barrier(0);
       stage = (stage + 1) & (GR_NSTAGE - 1);
     }
-    // ---- flush: this workgroup's partial lower triangle of G_d.  acc[b][e] of lane (li, lk) is
-    //      G[16 r + 4 (li >> 2) + lk][16 c + 4 (li & 3) + e]
+    // ---- flush: this segment's partial lower triangle, block by block (canonical block id r (r + 1) / 2 + c), each
+    //      lane's four values contiguous: acc[b][e] of lane (li, lk) is G[16 r + 4 (li >> 2) + lk][16 c + 4 (li & 3) + e]
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // (the requests past the range)
     __builtin_amdgcn_s_barrier();
     {
-      const int back = stage * GR_STAGE;       // the next d starts in stage 0 again
-#pragma unroll
-      for (int qq = 0; qq < NG; ++qq)
-#pragma unroll
-        for (int ri = 0; ri < GM::m.nr[qq]; ++ri) bA[qq][ri] -= back;
-      bB0 -= back; bB1 -= back;
+      const int back = stage * GR_STAGE;       // the next segment starts in stage 0 again
+      bA -= back; bB0 -= back; bB1 -= back;
     }
-    double* __restrict__ Gd = g.G + (long)d * 256 * 256 + (long)(4 * (li >> 2) + lk) * 256 + 4 * (li & 3);
+    double* __restrict__ slot = g.ws + ((long)blockIdx.x * 2 + seg) * GR_SLOT_DOUBLES + lane * 4;
     w_static_for<0, NS>([&](auto xc) __attribute__((always_inline)) {
       constexpr int x = decltype(xc)::value, q = u_grp(x), ci = u_ci(x);
       w_static_for<0, GM::m.nr[q]>([&](auto rc) __attribute__((always_inline)) {
         constexpr int ri = decltype(rc)::value;
         if constexpr ((GM::m.mask[q][ci] >> ri) & 1u) {
           constexpr int b = gram_blk(GM::m, q, ci, ri);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) unsafeAtomicAdd(Gd + (long)GM::m.rows[q][ri] * 16 * 256 + GM::m.cols[q][ci] * 16 + e, acc[b][e]);
+          constexpr int r = GM::m.rows[q][ri], c = GM::m.cols[q][ci];
+          const d4_t v = {acc[b][0], acc[b][1], acc[b][2], acc[b][3]};
+          *reinterpret_cast<d4_t*>(slot + (r * (r + 1) / 2 + c) * 256) = v;
         }
       });
     });
@@ -311,7 +335,6 @@ void gemm_gram_kernel(GramArgs g) {
   }
 }
 
-bool gemm_gram_ok(const GemmArgs& a);                    // a TN product this kernel can take (gemm_wide.hip)
-hipError_t gemm_gram(hipStream_t st, const GemmArgs& a);
+// host side: gemm_gram_ok / gemm_gram / gemm_gram_ws_bytes (gemm_gram.hip, declared in gemm_f64.h)
 
 }  // namespace dgp

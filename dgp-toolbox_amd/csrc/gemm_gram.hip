@@ -5,6 +5,43 @@
 
 namespace dgp {
 
+// G[d] += sum of the partial triangles of d.  One workgroup of 256 threads per (block, d): thread = lane * 4 + e.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(GramArgs g, int grid) {
+  const int id = blockIdx.x, d = blockIdx.y, t = threadIdx.x;
+  const long KT = g.P / 16, F = KT * g.D;
+  const long lo = (long)d * KT, hi = lo + KT;
+  // workgroups whose range meets [lo, hi): b from the one that contains lo
+  long b = (lo * grid) / F;
+  while (b > 0 && gram_cut(F, b, grid) > lo) --b;
+  while (gram_cut(F, b + 1, grid) <= lo) ++b;
+  double sum = 0.0;
+  for (; b < grid && gram_cut(F, b, grid) < hi; ++b) {
+    const long f_lo = gram_cut(F, b, grid);
+    const int seg = d - (int)(f_lo / KT);                  // 0 or 1
+    if (gram_cut(F, b + 1, grid) <= f_lo) continue;        // (empty range)
+    sum += g.ws[(b * 2 + seg) * GR_SLOT_DOUBLES + (long)id * 256 + t];
+  }
+  int r = 0;
+  while ((r + 1) * (r + 2) / 2 <= id) ++r;
+  const int c = id - r * (r + 1) / 2;
+  const int lane = t >> 2, e = t & 3, li = lane & 15, lk = lane >> 4;
+  g.G[(long)d * 65536 + (long)(16 * r + 4 * (li >> 2) + lk) * 256 + 16 * c + 4 * (li & 3) + e] += sum;
+}
+
+static int gram_grid() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    else cus = 256;
+    const char* e = getenv("DGP_GRAM_GRID");
+    if (e && atoi(e) > 0) cus = atoi(e);
+  }
+  return cus;
+}
+
+long gemm_gram_ws_bytes() { return 2L * gram_grid() * GR_SLOT_BYTES; }
+
 bool gemm_gram_ok(const GemmArgs& a) {
   static int enabled = -1;
   static long min_k = 0;
@@ -17,7 +54,7 @@ bool gemm_gram_ok(const GemmArgs& a) {
   if (!enabled) return false;
   if (a.A != a.B || a.M != 256 || a.N != 256 || a.lda != 256 || a.ldb != 256 || a.ldc != 256) return false;
   if (a.tri != TRI_OUT_LOWER || a.triblk != 256 || a.alpha != 1.0) return false;
-  if (!(a.beta == 1 || a.splits > 1)) return false;                         // the kernel ADDS its partial triangles
+  if (!(a.beta == 1 || a.splits > 1)) return false;                         // the triangles are ADDED to C
   if (a.K < min_k || a.K % 16 != 0) return false;
   if (a.batch < 1 || a.batch > 16 || (a.batch > 1 && (a.sC != 65536 || a.sA != 0 || a.sB != 0))) return false;
   if (a.ascale_mode == 2) { if (a.ascale == nullptr || a.as_ld != a.batch) return false; }
@@ -25,28 +62,22 @@ bool gemm_gram_ok(const GemmArgs& a) {
   if (a.epi != 0 || a.rank != 0 || a.eadd != nullptr || a.C2 != nullptr || a.a_blocked || a.c_blocked || a.tri_row0 != 0) return false;
   if ((reinterpret_cast<uintptr_t>(a.A) & 15u) || (reinterpret_cast<uintptr_t>(a.C) & 7u)) return false;
   if (a.ascale && (reinterpret_cast<uintptr_t>(a.ascale) & 15u)) return false;
+  if (a.gram_ws == nullptr || a.gram_ws_bytes < gemm_gram_ws_bytes() || (reinterpret_cast<uintptr_t>(a.gram_ws) & 31u)) return false;
   return true;
 }
 
 hipError_t gemm_gram(hipStream_t st, const GemmArgs& a) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-    else cus = 256;
-    const char* e = getenv("DGP_GRAM_GRID");
-    if (e && atoi(e) > 0) cus = atoi(e);
-  }
   GramArgs g;
   g.C = a.A;
   g.s = a.ascale_mode == 2 ? a.ascale : nullptr;
   g.G = a.C;
+  g.ws = a.gram_ws;
   g.P = a.K;
   g.D = a.batch;
-  const long kt = a.K / 16;
-  const unsigned grid = (unsigned)(kt < cus ? kt : cus);
+  const unsigned grid = (unsigned)gram_grid();          // (K >= min_k: every workgroup has k-tiles)
   if (g.s) hipLaunchKernelGGL(gemm_gram_kernel<true>, dim3(grid), dim3(512), 0, st, g);
   else hipLaunchKernelGGL(gemm_gram_kernel<false>, dim3(grid), dim3(512), 0, st, g);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(136, g.D), dim3(256), 0, st, g, (int)grid);
   return hipGetLastError();
 }
 
