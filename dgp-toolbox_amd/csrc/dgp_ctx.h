@@ -688,6 +688,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     {
       GemmArgs a = mk(Mp, Mp, Pl, ctx->Kbar, Mp, y.Ct, Mp, acc + y.acc_Q, Mp, 1.0, 1);
       a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp), Pl, (long)Mp * 16);
+      a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = ctx->gram_ws ? gemm_gram_ws_bytes() : 0;     // (Mp = 256: gemm_gram.h, two sources)
       RET(GX(ctx, 0, GEMM_TN, a, tri1, (double)Pl * Mp * 16));
     }
     {

@@ -33,18 +33,29 @@
 
 namespace dgp {
 
+// The MFMAs are issued through inline asm with the accumulator TIED (dst = srcC).  hipcc's builtin leaves dst free: with
+// 136 accumulator values, 272 MFMAs per loop body and every other register in use it renames accumulators, reaches
+// the 256-VGPR limit and spills in one or another wave's loop depending on details of the source (a spill reload waits
+// vmcnt(0), i.e. drains the DMA queue).  Tied: 199-203 VGPRs, no spill, in every specialisation.  The compiler does not
+// see an MFMA in the asm: no hazard handling (the accumulators are only read again after a barrier; dependent MFMAs
+// are >= 64 instructions apart) and no MFMA class for sched_group_barrier (units are fenced with sched_barrier).
+#ifndef GR_ASM_MFMA
+#define GR_ASM_MFMA 1
+#endif
+
 constexpr int GR_STAGE_B = 16 * 256 * 8;        // 32 KB: [16 k][128 chunks of 16 B], chunk ^ ((k >> 1) & 1)
-constexpr int GR_STAGE_S = 2048;                // 16 points x up to 16 weights
+constexpr int GR_STAGE_S = 2048;                // 16 points x up to 8 weights (1 KB) + spare
 constexpr int GR_STAGE = GR_STAGE_B + GR_STAGE_S;
 constexpr int GR_NSTAGE = 4;
 
 struct GramArgs {
+  const double* A;      // two-source form: [P][256] point-major, the ROW operand (G = A^T C); nullptr = C
   const double* C;      // [P][256] point-major (Ct)
   const double* s;      // [P][D] weights (vbar), or nullptr = 1
   double* G;            // [D][256][256]: the lower triangles are ADDED to it (by gram_reduce_kernel)
   double* ws;           // partial triangles: [2 * gridDim.x slots][136 blocks][64 lanes][4]  (GR_SLOT_BYTES each)
   long P;               // points, a multiple of 16
-  int D;                // 1..16
+  int D;                // 1..8
 };
 constexpr long GR_SLOT_DOUBLES = 136L * 256;
 constexpr long GR_SLOT_BYTES = GR_SLOT_DOUBLES * 8;
@@ -112,7 +123,7 @@ constexpr int gram_nblk(const GramMap& m) { return gram_blk(m, m.ng, 0, 0); }
 
 template <int W> struct GramMapOf { static constexpr GramMap m = gram_map(W); };
 
-template <int W, bool SC>
+template <int W, bool SC, int KH>
 __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wave, int lane) {
   using GM = GramMapOf<W>;
   constexpr int NG = GM::m.ng, NS = gram_units(GM::m);
@@ -120,14 +131,18 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
   constexpr int NB = gram_nblk(GM::m);
   static_assert(NB == 17, "every wave owns 17 blocks");
   constexpr int U = 4 * NS;                       // units per k-tile: (substep, group, column index)
-  constexpr int UB = 2 * NS;                      // the unit that carries the k-tile's barrier
+  // KH = 1: one source (A = C), a stage = 16 points.  KH = 2: two sources (rows from g.A, columns from g.C), a stage =
+  // 8 points of both (two 16 KB images): the loop body still covers 16 points, as two halves with a barrier each.
+  constexpr int SUBH = 4 / KH;                    // k-substeps per stage
+  constexpr int IMG_B = KH == 2 ? 16384 : 0;      // the column operand's image inside a stage (the row operand's is at 0)
+  static_assert(!(SC && KH == 2), "the weighted form has one source");
   static_assert(U % 4 == 0 && GM::m.nc[NG - 1] >= 2, "slot ring / barrier placement");
   const int li = lane & 15, lk = lane >> 4;
   const int sw = lk & 1;
   // (all fragment addresses include the current stage: they are advanced at every k-tile barrier)
   // B fragment of column block c, substep (s8, q): k = 8 s8 + 2 lk + q, 32 contiguous bytes at columns 16 c + 4 (li & 3),
   // the two 16-byte halves swapped when (k >> 1) & 1 = lk & 1
-  unsigned bB0 = (unsigned)((2 * lk) * 2048 + (li & 3) * 32 + sw * 16), bB1 = (unsigned)((2 * lk) * 2048 + (li & 3) * 32 + (1 - sw) * 16);
+  unsigned bB0 = (unsigned)(IMG_B + (2 * lk) * 2048 + (li & 3) * 32 + sw * 16), bB1 = (unsigned)(IMG_B + (2 * lk) * 2048 + (li & 3) * 32 + (1 - sw) * 16);
   // A fragment of row block r: element (k, m = 16 r + li) of the same image: chunk m / 2 = 8 r + (li >> 1), swizzled
   // (bit 0 only), + (m & 1) * 8: ONE per-lane address, the row block is a compile-time offset of 128 r bytes
   unsigned bA = (unsigned)((2 * lk) * 2048 + (((li >> 1) ^ sw) << 4) + (li & 1) * 8);
@@ -137,25 +152,37 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
   long kt_lo = 0;             // current segment: k-tiles [kt_lo, kt_lo + nkt) of output d
   int nkt = 0;
 
-  const bool two = g.D > 8;
-  const bool extra = SC && (W == 0 || (W == 1 && two));      // this wave also requests a piece of the weights
+  constexpr bool extra = SC && W == 0;      // this wave also requests the weights' piece
   // DMA: the B image = 32 pieces of 1 KB (half a k row each): wave w issues pieces 4 w .. 4 w + 3 (k rows 2 w, 2 w + 1);
-  // the weights (16 x D doubles, contiguous) = 1 piece (D <= 8) or 2 (D <= 16), requested by wave 0 / waves 0 and 1
-  const unsigned offB = (unsigned)((lane ^ (wave & 1)) * 16);
-  auto issue = [&](long kt, int stage) __attribute__((always_inline)) {
-    const double* ub = g.C + (kt * 16 + wave * 2) * 256;
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(ub), 0, 0x7ffffff0, 0x00020000);
+  // the weights (16 x D doubles, contiguous, D <= 8) = 1 piece, requested by wave 0
+  // KH = 2: each image = 16 pieces (8 k rows): wave w requests row w of both
+  const unsigned offB = (unsigned)((lane ^ (KH == 2 ? (wave >> 1) & 1 : wave & 1)) * 16);
+  const double* srcA = KH == 2 ? g.A : g.C;
+  auto issue = [&](long kt, int h, int stage) __attribute__((always_inline)) {
     char* base = smem + stage * GR_STAGE;
+    if constexpr (KH == 1) {
+      const double* ub = g.C + (kt * 16 + wave * 2) * 256;
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(ub), 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, W_LDS3(base + (wave * 4 + p) * 1024), 16, offB, (p >> 1) * 2048 + (p & 1) * 1024, 0, 0);
-    if constexpr (SC && W <= 1) {
-      if (extra) {
+      for (int p = 0; p < 4; ++p)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, W_LDS3(base + (wave * 4 + p) * 1024), 16, offB, (p >> 1) * 2048 + (p & 1) * 1024, 0, 0);
+    } else {
+      const long row = kt * 16 + h * 8 + wave;
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(srcA + row * 256), 0, 0x7ffffff0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(g.C + row * 256), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, W_LDS3(base + (wave * 2 + p) * 1024), 16, offB, p * 1024, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, W_LDS3(base + IMG_B + (wave * 2 + p) * 1024), 16, offB, p * 1024, 0, 0);
+      }
+    }
+    if constexpr (extra) {
+      {
         // rows 16 kt .. 16 kt + 15 of s: 16 D doubles from s + 16 kt D; reads past the end of s return zeros (num_records)
-        const long off = kt * 16 * g.D * 8 + W * 1024, left = g.P * g.D * 8 - off;
+        const long off = kt * 16 * g.D * 8, left = g.P * g.D * 8 - off;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(reinterpret_cast<const char*>(g.s) + off), 0, (int)(left > 0x7ffffff0 ? 0x7ffffff0 : (left > 0 ? left : 0)), 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, W_LDS3(base + GR_STAGE_B + W * 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, W_LDS3(base + GR_STAGE_B), 16, (unsigned)(lane * 16), 0, 0, 0);
       }
     }
   };
@@ -167,6 +194,8 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
     if (extra) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   };
   auto kt_of = [&](int i) { return kt_lo + (i < nkt ? i : nkt - 1); };   // requests past the range re-read its last k-tile
+  // stage x (counted from the segment's start) -> its 16-point k-tile and half
+  auto issue_x = [&](int x, int stage) __attribute__((always_inline)) { issue(kt_of(x / KH), x % KH, stage); };
 
   double acc[NB][4];
   double fb[4][4];              // ring of four units: [slot][e]
@@ -183,7 +212,7 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
   auto u_grp = [](int u) constexpr { return (u % NS) < GM::m.nc[0] ? 0 : 1; };
   auto u_ci = [](int u) constexpr { return (u % NS) < GM::m.nc[0] ? (u % NS) : (u % NS) - GM::m.nc[0]; };
   auto uoff = [&](int u) constexpr {
-    const int sub = u_sub(u);
+    const int sub = u_sub(u) % SUBH;
     return (unsigned)((8 * (sub >> 1) + (sub & 1)) * 2048 + GM::m.cols[u_grp(u)][u_ci(u)] * 128);
   };
 
@@ -200,7 +229,7 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
     const unsigned wstep = (unsigned)(g.D * 8);
     // raw A fragments (and the weight) of phase ph = substep * NG + group
     auto rawA = [&](auto phc) __attribute__((always_inline)) {
-      constexpr int ph = decltype(phc)::value, sub = ph / NG, q = ph % NG;
+      constexpr int ph = decltype(phc)::value, sub = (ph / NG) % SUBH, q = ph % NG;
       constexpr unsigned ko = (unsigned)((8 * (sub >> 1) + (sub & 1)) * 2048);
 #pragma unroll
       for (int ri = 0; ri < GM::m.nr[q]; ++ri) fr[ri] = *reinterpret_cast<const double*>(smem + bA + (ko + GM::m.rows[q][ri] * 128));
@@ -208,9 +237,9 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
     };
 
     // ---- prologue: three k-tiles requested, the first one landed and published
-    issue(kt_of(0), 0);
-    issue(kt_of(1), 1);
-    issue(kt_of(2), 2);
+    issue_x(0, 0);
+    issue_x(1, 1);
+    issue_x(2, 2);
     wait_tiles2();
     __builtin_amdgcn_s_barrier();
     int stage = 0;
@@ -219,7 +248,9 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
     readB(1, uoff(1));
 
     for (int i = 0; i < nkt; ++i) {
-      const int dstep = stage == GR_NSTAGE - 1 ? -(GR_NSTAGE - 1) * GR_STAGE : GR_STAGE;
+      // address step out of the stage of half 0 / half 1 of this iteration
+      const int dstep0 = stage == GR_NSTAGE - 1 ? -(GR_NSTAGE - 1) * GR_STAGE : GR_STAGE;
+      const int dstep1 = ((stage + 1) & (GR_NSTAGE - 1)) == GR_NSTAGE - 1 ? -(GR_NSTAGE - 1) * GR_STAGE : GR_STAGE;
       // unit u = (substep, group, column index): its B fragment sits in slot u & 3 and was read two units earlier
       w_static_for<0, U>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value, sub = u_sub(u), q = u_grp(u), ci = u_ci(u), ph = sub * NG + q;
@@ -229,17 +260,18 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
           for (int ri = 0; ri < GM::m.nr[q]; ++ri) fa[ri] = SC ? fr[ri] * fw : fr[ri];
           // raw fragments of the next phase; the k-tile's last phase reads those of the NEXT k-tile's first one (its
           // stage was published by this k-tile's barrier)
-          if constexpr (ph + 1 < 4 * NG) {
+          if constexpr ((ph + 1) % (SUBH * NG) != 0) {
             rawA(std::integral_constant<int, ph + 1>{});
           } else {
-            bA += dstep; wbase += dstep;
-            rawA(std::integral_constant<int, 0>{});
+            { const int ds = (ph / (SUBH * NG)) == 0 ? dstep0 : dstep1; bA += ds; wbase += ds; }
+            rawA(std::integral_constant<int, (ph + 1) % (4 * NG)>{});
           }
           // (fence: left to itself the scheduler sinks these reads to the last LDS slots before their first use, which
           //  for the k-tile's last phase is the top of the next iteration)
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (u == UB) {
+        if constexpr (u % (SUBH * NS) == (SUBH / 2) * NS) {
+          constexpr int h = u / (SUBH * NS);
           // mid k-tile: this wave's pieces of the NEXT k-tile have landed (the one after it may stay in flight); the
           // barrier publishes the next k-tile and certifies that every wave has left the PREVIOUS k-tile, whose stage
           // takes the request for the k-tile three ahead.  (No LDS read has to be complete here: the current stage is
@@ -251,12 +283,12 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
 #endif
           __builtin_amdgcn_sched_barrier(0);
 #ifndef GR_ABL_NODMA
-          issue(kt_of(i + 3), (stage + 3) & (GR_NSTAGE - 1));
+          issue_x(KH * i + h + 3, (stage + h + 3) & (GR_NSTAGE - 1));
 #endif
         }
-        if constexpr (u == U - 2) {
-          // from here on the B fragment reads belong to the next k-tile
-          bB0 += dstep; bB1 += dstep;
+        if constexpr (u % (SUBH * NS) == SUBH * NS - 2) {
+          // from here on the B fragment reads belong to the next stage
+          { const int ds = (u / (SUBH * NS)) == 0 ? dstep0 : dstep1; bB0 += ds; bB1 += ds; }
         }
         readB((u + 2) & 3, uoff((u + 2) % U));
         w_static_for<0, GM::m.nr[q]>([&](auto rc) __attribute__((always_inline)) {
@@ -264,14 +296,26 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
           if constexpr ((GM::m.mask[q][ci] >> ri) & 1u) {
             constexpr int b = gram_blk(GM::m, q, ci, ri);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[b][e] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[ri], fb[u & 3][e], acc[b][e], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+#if GR_ASM_MFMA
+              double c_ = acc[b][e];
+              const double a_ = fa[ri], b_ = fb[u & 3][e];
+              asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(c_) : "v"(a_), "v"(b_));
+              acc[b][e] = c_;
+#else
+              acc[b][e] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[ri], fb[u & 3][e], acc[b][e], 0, 0, 0);
+#endif
+            }
           }
         });
         // issue order inside the unit: its first MFMA (it carries the wait for the fragments), then one LDS read per MFMA
         constexpr int nm = 4 * gr_popc(GM::m.mask[q][ci]);
+#if GR_ASM_MFMA
+        __builtin_amdgcn_sched_barrier(0);
+#else
         {
           constexpr int n_ds = 2;
-          constexpr int n_vm = u == UB ? 4 : 0;                 // (the fifth request of waves 0 / 1 floats)
+          constexpr int n_vm = (u % (SUBH * NS) == (SUBH / 2) * NS) ? 4 : 0;                 // (the fifth request of waves 0 / 1 floats)
           constexpr int n_il = n_ds + n_vm < nm - 1 ? n_ds + n_vm : nm - 1;
           constexpr int n_il_vm = n_vm < n_il ? n_vm : n_il, n_il_ds = n_il - n_il_vm;
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -287,9 +331,10 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
           if constexpr (n_ds > n_il_ds) __builtin_amdgcn_sched_group_barrier(0x100, n_ds - n_il_ds, 0);
           if constexpr (nm - 1 - n_il > 0) __builtin_amdgcn_sched_group_barrier(0x008, nm - 1 - n_il, 0);
         }
+#endif
       });
       __builtin_amdgcn_sched_barrier(0);
-      stage = (stage + 1) & (GR_NSTAGE - 1);
+      stage = (stage + KH) & (GR_NSTAGE - 1);
     }
     // ---- flush: this segment's partial lower triangle, block by block (canonical block id r (r + 1) / 2 + c), each
     //      lane's four values contiguous: acc[b][e] of lane (li, lk) is G[16 r + 4 (li >> 2) + lk][16 c + 4 (li & 3) + e]
@@ -317,21 +362,21 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
   }
 }
 
-template <bool SC>
+template <bool SC, int KH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_gram_kernel(GramArgs g) {
   __shared__ __attribute__((aligned(1024))) char smem[GR_NSTAGE * GR_STAGE];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   switch (wave) {
-    case 0: gram_wave<0, SC>(g, smem, wave, lane); break;
-    case 1: gram_wave<1, SC>(g, smem, wave, lane); break;
-    case 2: gram_wave<2, SC>(g, smem, wave, lane); break;
-    case 3: gram_wave<3, SC>(g, smem, wave, lane); break;
-    case 4: gram_wave<4, SC>(g, smem, wave, lane); break;
-    case 5: gram_wave<5, SC>(g, smem, wave, lane); break;
-    case 6: gram_wave<6, SC>(g, smem, wave, lane); break;
-    default: gram_wave<7, SC>(g, smem, wave, lane); break;
+    case 0: gram_wave<0, SC, KH>(g, smem, wave, lane); break;
+    case 1: gram_wave<1, SC, KH>(g, smem, wave, lane); break;
+    case 2: gram_wave<2, SC, KH>(g, smem, wave, lane); break;
+    case 3: gram_wave<3, SC, KH>(g, smem, wave, lane); break;
+    case 4: gram_wave<4, SC, KH>(g, smem, wave, lane); break;
+    case 5: gram_wave<5, SC, KH>(g, smem, wave, lane); break;
+    case 6: gram_wave<6, SC, KH>(g, smem, wave, lane); break;
+    default: gram_wave<7, SC, KH>(g, smem, wave, lane); break;
   }
 }
 

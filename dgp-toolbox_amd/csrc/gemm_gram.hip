@@ -5,22 +5,33 @@
 
 namespace dgp {
 
-// G[d] += sum of the partial triangles of d.  One workgroup of 256 threads per (block, d): thread = lane * 4 + e.
+// G[d] += sum of the partial triangles of d, in a fixed order.  One workgroup of 256 threads per (block, d): thread =
+// lane * 4 + e.  The workgroups whose ranges meet d's k-tiles [lo, hi) are consecutive; only the first of them can have
+// started in d - 1 (its partial of d is then its SECOND segment).
 __global__ __launch_bounds__(256) void gram_reduce_kernel(GramArgs g, int grid) {
   const int id = blockIdx.x, d = blockIdx.y, t = threadIdx.x;
   const long KT = g.P / 16, F = KT * g.D;
   const long lo = (long)d * KT, hi = lo + KT;
-  // workgroups whose range meets [lo, hi): b from the one that contains lo
-  long b = (lo * grid) / F;
-  while (b > 0 && gram_cut(F, b, grid) > lo) --b;
-  while (gram_cut(F, b + 1, grid) <= lo) ++b;
-  double sum = 0.0;
-  for (; b < grid && gram_cut(F, b, grid) < hi; ++b) {
-    const long f_lo = gram_cut(F, b, grid);
-    const int seg = d - (int)(f_lo / KT);                  // 0 or 1
-    if (gram_cut(F, b + 1, grid) <= f_lo) continue;        // (empty range)
-    sum += g.ws[(b * 2 + seg) * GR_SLOT_DOUBLES + (long)id * 256 + t];
+  long b0 = (lo * grid) / F;
+  while (b0 > 0 && gram_cut(F, b0, grid) > lo) --b0;
+  while (gram_cut(F, b0 + 1, grid) <= lo) ++b0;                 // first workgroup whose range ends after lo
+  long b1 = (hi * grid) / F;
+  if (b1 > grid) b1 = grid;
+  while (b1 < grid && gram_cut(F, b1, grid) < hi) ++b1;
+  while (b1 > b0 + 1 && gram_cut(F, b1 - 1, grid) >= hi) --b1;   // [b0, b1): ranges that start before hi
+  const double* __restrict__ w = g.ws + (long)id * 256 + t;
+  const int seg0 = d - (int)(gram_cut(F, b0, grid) / KT);
+  double sum = w[(b0 * 2 + seg0) * GR_SLOT_DOUBLES];
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  long b = b0 + 1;
+  for (; b + 8 <= b1; b += 8) {                                  // (eight independent loads in flight; fixed association)
+    double v[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] = w[(b + x) * 2 * GR_SLOT_DOUBLES];
+    sum += v[0] + v[4]; s1 += v[1] + v[5]; s2 += v[2] + v[6]; s3 += v[3] + v[7];
   }
+  for (; b < b1; ++b) sum += w[b * 2 * GR_SLOT_DOUBLES];
+  sum = (sum + s1) + (s2 + s3);
   int r = 0;
   while ((r + 1) * (r + 2) / 2 <= id) ++r;
   const int c = id - r * (r + 1) / 2;
@@ -52,15 +63,16 @@ bool gemm_gram_ok(const GemmArgs& a) {
     min_k = k ? atol(k) : 65536;       // below that a workgroup's range is a few k-tiles: the split-K engine is as good
   }
   if (!enabled) return false;
-  if (a.A != a.B || a.M != 256 || a.N != 256 || a.lda != 256 || a.ldb != 256 || a.ldc != 256) return false;
+  if (a.M != 256 || a.N != 256 || a.lda != 256 || a.ldb != 256 || a.ldc != 256) return false;
   if (a.tri != TRI_OUT_LOWER || a.triblk != 256 || a.alpha != 1.0) return false;
   if (!(a.beta == 1 || a.splits > 1)) return false;                         // the triangles are ADDED to C
   if (a.K < min_k || a.K % 16 != 0) return false;
-  if (a.batch < 1 || a.batch > 16 || (a.batch > 1 && (a.sC != 65536 || a.sA != 0 || a.sB != 0))) return false;
+  if (a.batch < 1 || a.batch > 8 || (a.batch > 1 && (a.sC != 65536 || a.sA != 0 || a.sB != 0))) return false;
   if (a.ascale_mode == 2) { if (a.ascale == nullptr || a.as_ld != a.batch) return false; }
   else if (a.ascale_mode != 0 || a.batch != 1) return false;
+  if (a.A != a.B && (a.ascale_mode != 0 || a.batch != 1)) return false;                  // two sources: unweighted, one output
   if (a.epi != 0 || a.rank != 0 || a.eadd != nullptr || a.C2 != nullptr || a.a_blocked || a.c_blocked || a.tri_row0 != 0) return false;
-  if ((reinterpret_cast<uintptr_t>(a.A) & 15u) || (reinterpret_cast<uintptr_t>(a.C) & 7u)) return false;
+  if ((reinterpret_cast<uintptr_t>(a.A) & 15u) || (reinterpret_cast<uintptr_t>(a.B) & 15u) || (reinterpret_cast<uintptr_t>(a.C) & 7u)) return false;
   if (a.ascale && (reinterpret_cast<uintptr_t>(a.ascale) & 15u)) return false;
   if (a.gram_ws == nullptr || a.gram_ws_bytes < gemm_gram_ws_bytes() || (reinterpret_cast<uintptr_t>(a.gram_ws) & 31u)) return false;
   return true;
@@ -68,15 +80,17 @@ bool gemm_gram_ok(const GemmArgs& a) {
 
 hipError_t gemm_gram(hipStream_t st, const GemmArgs& a) {
   GramArgs g;
-  g.C = a.A;
+  g.A = a.A == a.B ? nullptr : a.A;
+  g.C = a.B;
   g.s = a.ascale_mode == 2 ? a.ascale : nullptr;
   g.G = a.C;
   g.ws = a.gram_ws;
   g.P = a.K;
   g.D = a.batch;
   const unsigned grid = (unsigned)gram_grid();          // (K >= min_k: every workgroup has k-tiles)
-  if (g.s) hipLaunchKernelGGL(gemm_gram_kernel<true>, dim3(grid), dim3(512), 0, st, g);
-  else hipLaunchKernelGGL(gemm_gram_kernel<false>, dim3(grid), dim3(512), 0, st, g);
+  if (g.A) hipLaunchKernelGGL((gemm_gram_kernel<false, 2>), dim3(grid), dim3(512), 0, st, g);
+  else if (g.s) hipLaunchKernelGGL((gemm_gram_kernel<true, 1>), dim3(grid), dim3(512), 0, st, g);
+  else hipLaunchKernelGGL((gemm_gram_kernel<false, 1>), dim3(grid), dim3(512), 0, st, g);
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(136, g.D), dim3(256), 0, st, g, (int)grid);
   return hipGetLastError();
 }
