@@ -340,6 +340,9 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
     //      lane's four values contiguous: acc[b][e] of lane (li, lk) is G[16 r + 4 (li >> 2) + lk][16 c + 4 (li & 3) + e]
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // (the requests past the range)
     __builtin_amdgcn_s_barrier();
+#if GR_ASM_MFMA
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");               // MFMA results -> stores: the wait states hipcc cannot see
+#endif
     {
       const int back = stage * GR_STAGE;       // the next segment starts in stage 0 again
       bA -= back; bB0 -= back; bB1 -= back;
