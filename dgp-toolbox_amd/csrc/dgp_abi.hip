@@ -329,9 +329,6 @@ int dgp_propagate_full_cov(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t
   double *Kt = nullptr, *Ct = nullptr, *T = nullptr, *mean0 = nullptr, *mean = nullptr, *Kff = nullptr, *V = nullptr,
          *Vinv = nullptr, *tmp = nullptr, *var_dev = nullptr, *Fa = nullptr, *Fb = nullptr, *X0 = nullptr;
   const long NN = (long)Np * Np;
-  for (auto& y : ctx->L)
-    if (y.d.kernel_kind == DGP_KERNEL_MF || y.off_white >= 0)
-      return fail(ctx, DGP_ERR_INVALID, "dgp_propagate_full_cov: stationary kernels without a White term only");
   struct Free {
     std::vector<double**> ps;
     ~Free() { for (auto p : ps) dev_free(*p); }
@@ -353,8 +350,11 @@ int dgp_propagate_full_cov(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t
     for (int s = 0; s < S; ++s) {
       const double* Xs = (l == 0) ? X0 : Fin + (long)s * N * Din;
       HIPCHK(hipMemsetAsync(Kt, 0, (size_t)Pm * Mp * 8, ctx->st));            // pad rows of every product stay zero
-      HIPCHK(rbf_kuf(ctx->st, y.d.kernel_kind, Xs, N, 0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), y.d.M, Mp, Din,
-                     Kt, nullptr));
+      if (y.d.kernel_kind == DGP_KERNEL_MF)           // the composite kernel on [x, f] (mfkern.hip)
+        HIPCHK(mf_kuf(ctx->st, Xs, N, 0, P(ctx, y.off_Z), P(ctx, y.off_var), y.d.M, Mp, Din, Kt));
+      else
+        HIPCHK(rbf_kuf(ctx->st, y.d.kernel_kind, Xs, N, 0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), y.d.M, Mp, Din,
+                       Kt, nullptr));
       {
         GemmArgs a = mk(Pm, Mp, Mp, Kt, Mp, y.Linv, Mp, Ct, Mp);
         a.tri = TRI_B_UPPER; a.triblk = Mp;
@@ -368,7 +368,12 @@ int dgp_propagate_full_cov(dgp_ctx* ctx, const double* Xnew, int64_t Nn, int32_t
       RET(GX(ctx, 0, GEMM_NN, mk(Pm, D, Mp, Ct, Mp, y.u, D, mean0, D)));
       HIPCHK(fc_mean(ctx->st, mean0, Xs, N, Din, D, y.d.mean_kind, y.meanW, y.meanb, mean));
       // V_d = K(X_s, X_s) + jitter I - C C^T + T_d T_d^T   (layers.py:265-268 in whitened form; jitter: utils.py:47)
-      HIPCHK(rbf_kuu(ctx->st, y.d.kernel_kind, Xs, P(ctx, y.off_var), P(ctx, y.off_ls), (int)N, Np, Din, Kff, nullptr));
+      //   K(X_s, X_s) of a kernel with a White term carries its variance on the diagonal (kern.K(X), layers.py:265)
+      if (y.d.kernel_kind == DGP_KERNEL_MF)
+        HIPCHK(mf_kuu(ctx->st, Xs, P(ctx, y.off_var), (int)N, Np, Din, Kff));
+      else
+        HIPCHK(rbf_kuu(ctx->st, y.d.kernel_kind, Xs, P(ctx, y.off_var), P(ctx, y.off_ls), (int)N, Np, Din, Kff, nullptr));
+      if (y.off_white >= 0) HIPCHK(add_diag_dev(ctx->st, Kff, (int)N, Np, P(ctx, y.off_white)));
       for (int d = 0; d < D; ++d) HIPCHK(copy_mat(ctx->st, Kff, V + (long)d * NN, NN));
       {
         GemmArgs a = mk(Np, Np, Mp, Ct, Mp, Ct, Mp, V, Np, -1.0, 1);

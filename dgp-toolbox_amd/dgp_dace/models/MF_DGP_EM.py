@@ -170,6 +170,12 @@ class SVGP_Layer:
         Fs, Fm, Fv = self._ctx.propagate(X, 1, 0, [z[None]])
         return Fs[0][0], Fm[0][0], Fv[0][0]
 
+    def forward_full_cov(self, X, z):
+        """full_cov=True for ONE sample (layers_red.py:63-80 maps the layer over the samples): X [N, D_in], z [N, D_out]
+        -> sample mean + chol(V + jitter) z [N, D], mean [N, D], covariance [N, N, D] (dgp_propagate_full_cov)."""
+        Fs, Fm, Fv = self._ctx.propagate_full_cov(X, 1, 0, [z[None]])
+        return Fs[0][0], Fm[0][0], Fv[0][0]
+
     def backward(self, X, z, f_bar=None, mean_bar=None, var_bar=None):
         """x-gradient of sum(cotangent * output); the parameter sums are added to this layer's accumulator."""
         bars = [None if b is None else np.ascontiguousarray(b)[None] for b in (f_bar, mean_bar, var_bar)]
@@ -394,10 +400,45 @@ class DGP_Base:
             lr, Hin, w = rec["red"][j]
             Hbar[j] = Hbar[j] + lr.backward(Hin, w, f_bar=hb)
 
+    def _chain_full_cov(self, X, S, zs, ws, fidelity_dim, project=False):
+        """propagate(full_cov=True) (MF_DGP_EM.py:123-168): every layer is evaluated sample by sample on its own N
+        inputs (conditional_SND, layers_red.py:63-80); covariances are [S, N, N, D]."""
+        L = len(self.layers_red)
+        parts = None
+        for s in range(S):
+            H = X
+            Hs, Hm, Hv = [H], [], []
+            for j, lr in enumerate(self.layers_red[L - fidelity_dim:]):
+                H, m, v = lr.forward_full_cov(H, np.ascontiguousarray(ws[j][s]))
+                Hs.append(H); Hm.append(m); Hv.append(v)
+            if project:
+                res = (Hs, Hm, Hv)
+            else:
+                Fs, Fm, Fv = [], [], []
+                F = None
+                for i in range(fidelity_dim + 1):
+                    inp = Hs[-1] if i == 0 else np.concatenate([Hs[-(i + 1)], F], 1)
+                    F, m, v = self.layers[i].forward_full_cov(inp, np.ascontiguousarray(zs[i][s]))
+                    Fs.append(F); Fm.append(m); Fv.append(v)
+                res = (Fs, Fm, Fv)
+            if parts is None:
+                parts = tuple([[t] for t in part] for part in res)
+            else:
+                for part, acc in zip(res, parts):
+                    for t, a in zip(part, acc):
+                        a.append(t)
+        return tuple([as_tensor(np.stack(a)) for a in part] for part in parts)
+
     def propagate(self, X, full_cov=False, S=1, zs=None, ws=None, fidelity_dim=None, project=False):
-        if full_cov:
-            raise NotImplementedError("full_cov=True is not implemented for the multi-fidelity model")
         X = np.ascontiguousarray(X, dtype=np.float64)
+        if full_cov:
+            L = len(self.layers_red)
+            fd = L if fidelity_dim is None else fidelity_dim
+            N = X.shape[0]
+            ws = ws if ws is not None else [self.rng.standard_normal((S, N, lr.num_outputs)) for lr in self.layers_red[L - fd:]]
+            zs = zs if zs is not None else [self.rng.standard_normal((S, N, 1)) for _ in range(fd + 1)]
+            self._sync_all()
+            return self._chain_full_cov(X, S, [np.asarray(z) for z in zs], [np.asarray(w) for w in ws], fd, project)
         L = len(self.layers_red)
         fd = L if fidelity_dim is None else fidelity_dim
         N = X.shape[0]
@@ -672,6 +713,13 @@ class MultiFidelityDeepGP_EM:
         y_m, y_v = self.model.predict_y(X_test, 250, full_cov=full_cov)
         y_m, y_v = np.asarray(y_m), np.asarray(y_v)
         mean = np.mean(y_m, axis=0).flatten()
+        if full_cov:
+            # MF_DGP_EM.py:419-425 adds np.mean(y_v, 0).flatten() (N*N values) to np.var(y_m, 0).flatten() (N values):
+            # that only broadcasts for N = 1.  The same two terms for any N (law of total covariance): the mean of the
+            # per-sample [N, N] covariances + the covariance of the per-sample means -> ([N, 1], [N, N]); for N = 1 it is
+            # the reference's value
+            dm = y_m[:, :, 0] - mean[None]
+            return mean[:, None], np.mean(y_v[..., 0], axis=0) + dm.T @ dm / y_m.shape[0]
         var = np.mean(y_v, axis=0).flatten() + np.var(y_m, axis=0).flatten()
         return mean[:, None], var[:, None]
 

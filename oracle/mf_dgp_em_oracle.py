@@ -194,6 +194,63 @@ def propagate(P, X, S, zs, ws, fidelity_dim, project=False):
     return Fs, Fmeans, Fvars
 
 
+def conditional_full(layer, Z, X):
+    """layers_red.py:237-272 with full_cov=True (non-white, Zero mean function): mean [N, D], var [N, N, D]."""
+    k = layer["kern"]
+    M, D = layer["q_mu"].shape
+    Ku = kern_K(k, Z) + JITTER * torch.eye(M, dtype=DT)
+    Lu = torch.linalg.cholesky(Ku)
+    Kuf = kern_K(k, Z, X)
+    A = torch.linalg.solve_triangular(Lu, Kuf, upper=False)
+    A = torch.linalg.solve_triangular(Lu.T, A, upper=True)
+    mean = A.T @ layer["q_mu"]
+    q_sqrt = torch.tril(layer["q_sqrt"])
+    SK = q_sqrt @ q_sqrt.transpose(1, 2) - Ku[None]
+    At = A[None].expand(D, -1, -1)
+    delta = At.transpose(1, 2) @ (SK @ At)                    # [D, N, N]
+    var = kern_K(k, X)[None] + delta                          # kern.K(X): a White term sits on the diagonal
+    return mean, var.permute(1, 2, 0)
+
+
+def sample_layer_full(layer, Z, X, z):
+    """sample_from_conditional(full_cov=True) + reparameterize (utils.py:43-51) for ONE sample: X [N, D_in], z [N, D]."""
+    mean, var = conditional_full(layer, Z, X)
+    N = X.shape[0]
+    chol = torch.linalg.cholesky(var.permute(2, 0, 1) + JITTER * torch.eye(N, dtype=DT)[None])     # [D, N, N]
+    f = mean + (chol @ z.T[:, :, None])[:, :, 0].T
+    return f, mean, var
+
+
+def propagate_full_cov(P, X, S, zs, ws, fidelity_dim, project=False):
+    """DGP_Base.propagate(full_cov=True) (MF_DGP_EM.py:123-168): conditional_SND maps the layer over the samples
+    (layers_red.py:63-80); returns per layer [S, N, D] samples / means and [S, N, N, D] covariances."""
+    L = len(P["layers_red"])
+    out = None
+    for s in range(S):
+        H = X
+        Hs, Hm, Hv = [H], [], []
+        for j, lr in enumerate(P["layers_red"][L - fidelity_dim:]):
+            H, m, v = sample_layer_full(lr, lr["Z"], H, ws[j][s])
+            Hs.append(H); Hm.append(m); Hv.append(v)
+        if project:
+            res = (Hs, Hm, Hv)
+        else:
+            Fs, Fm, Fv = [], [], []
+            F = None
+            for i in range(fidelity_dim + 1):
+                inp = Hs[-1] if i == 0 else torch.cat([Hs[-(i + 1)], F], 1)
+                F, m, v = sample_layer_full(P["layers"][i], P["_Zfull"][i], inp, zs[i][s])
+                Fs.append(F); Fm.append(m); Fv.append(v)
+            res = (Fs, Fm, Fv)
+        if out is None:
+            out = tuple([[t] for t in part] for part in res)
+        else:
+            for part, acc in zip(res, out):
+                for t, a in zip(part, acc):
+                    a.append(t)
+    return tuple([torch.stack(a) for a in part] for part in out)
+
+
 def _gauss_ve(mean, var, Y, s2, S):
     Yt = Y[None].expand(S, -1, -1).reshape(mean.shape)
     return -0.5 * math.log(2 * math.pi) - 0.5 * torch.log(s2) - 0.5 * ((Yt - mean) ** 2 + var) / s2

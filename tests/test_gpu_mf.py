@@ -343,3 +343,46 @@ def test_mf_dgp_em_against_the_committed_fixture():
         ref = g["g." + names[id(p)]].reshape(p._value.shape)
         np.testing.assert_allclose(np.asarray(grads[id(p)]).reshape(p._value.shape), ref, rtol=1e-6,
                                    atol=1e-7 * max(1.0, np.abs(ref).max()), err_msg=names[id(p)])
+
+
+@pytest.mark.parametrize("n_fid", [2, 3])
+def test_mf_propagate_full_cov_matches_the_restatement(n_fid):
+    """propagate(full_cov=True) of the multi-fidelity model (MF_DGP_EM.py:123-168 with layers_red.py:63-80,257-272 and
+    utils.py:43-51): samples, means and [S, N, N, D] covariances of every layer, with all normals injected, against the
+    torch restatement; then predict(full_cov=True) (MF_DGP_EM.py:419-425)."""
+    import torch
+    import mf_dgp_em_oracle as mo
+    rng = np.random.default_rng(5 + n_fid)
+    X, Y, X_red = _mf_problem(rng, n_fid)
+    S = 3
+    mf, P, names = _pair_models(rng, X, Y, X_red, S)
+    normals = mo.draw_normals(rng, X, P, S)
+    ref, _, _ = mo.elbo_and_grads(P, X, Y, X_red, normals, S)        # both sides now hold the same Z_right
+    assert abs(mf.model.ELBO((X, Y, X_red), normals=normals) - ref) <= 1e-8 * max(1.0, abs(ref))
+    N = 6
+    Xt = rng.uniform(0, 1, (N, X[-1].shape[1]))
+    L = len(mf.model.layers_red)
+    ws = [rng.standard_normal((S, N, lr.num_outputs)) for lr in mf.model.layers_red]
+    zs = [rng.standard_normal((S, N, 1)) for _ in range(L + 1)]
+    for project in (False, True):
+        got = mf.model.propagate(Xt, full_cov=True, S=S, zs=zs, ws=ws, project=project)
+        with torch.no_grad():
+            want = mo.propagate_full_cov(P, torch.as_tensor(Xt), S, [torch.as_tensor(z) for z in zs],
+                                         [torch.as_tensor(w) for w in ws], L, project=project)
+        for part_g, part_w, what in zip(got, want, ("sample", "mean", "cov")):
+            if project and what == "sample":
+                part_g, part_w = part_g[1:], part_w[1:]              # (the first entry is the input itself)
+            assert len(part_g) == len(part_w)
+            for l, (g, w) in enumerate(zip(part_g, part_w)):
+                g, w = np.asarray(g), w.numpy()
+                assert g.shape == w.shape, (what, l, g.shape, w.shape)
+                np.testing.assert_allclose(g, w, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(w).max()), err_msg=f"{what} {l}")
+    # predict_f / predict_y / predict with full_cov=True
+    Fm, Fv = mf.model.predict_f(Xt, full_cov=True, S=4)
+    assert np.asarray(Fm).shape == (4, N, 1) and np.asarray(Fv).shape == (4, N, N, 1)
+    mean, cov = mf.predict(Xt, full_cov=True)
+    assert mean.shape == (N, 1) and cov.shape == (N, N)
+    np.testing.assert_allclose(cov, cov.T, rtol=0, atol=1e-10)
+    assert np.all(np.linalg.eigvalsh(cov) > 0)
+    m1, c1 = mf.predict(Xt[:1], full_cov=True)                      # N = 1: the reference's own expression is defined
+    assert m1.shape == (1, 1) and c1.shape == (1, 1) and c1[0, 0] > 0
