@@ -980,11 +980,15 @@ int dgp_dev_gemm(dgp_ctx* ctx, int32_t op, int64_t M, int64_t N, int64_t K, cons
   HIPCHK(hipSetDevice(ctx->device));
   const long ar = (op == GEMM_TN) ? K : M, br = (op == GEMM_NT) ? N : K;
   double *dA, *dB, *dC;
+  const bool same = (A == B) && ar == br && lda == ldb;     // one operand passed twice stays ONE device buffer (Gram form)
   RET(dev_alloc(ctx, &dA, (size_t)ar * lda));
-  RET(dev_alloc(ctx, &dB, (size_t)br * ldb));
+  if (same) dB = dA; else RET(dev_alloc(ctx, &dB, (size_t)br * ldb));
   RET(dev_alloc(ctx, &dC, (size_t)M * ldc));
+  // reductions over the points with a 256 x 256 lower-triangular output: the Gram kernel's scratch (gemm_gram.h)
+  if (op == GEMM_TN && M == 256 && N == 256 && tri == TRI_OUT_LOWER && !ctx->gram_ws)
+    RET(dev_alloc(ctx, &ctx->gram_ws, gemm_gram_ws_bytes() / 8));
   HIPCHK(hipMemcpy(dA, A, (size_t)ar * lda * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dB, B, (size_t)br * ldb * 8, hipMemcpyHostToDevice));
+  if (!same) HIPCHK(hipMemcpy(dB, B, (size_t)br * ldb * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dC, C, (size_t)M * ldc * 8, hipMemcpyHostToDevice));
   int rc = G(ctx, 0, (GemmOp)op, M, N, K, dA, lda, dB, ldb, dC, ldc, alpha, beta, 1, 0, 0, 0, splits, tri, triblk);
   if (rc == DGP_OK) {
@@ -1004,7 +1008,8 @@ int dgp_dev_gemm(dgp_ctx* ctx, int32_t op, int64_t M, int64_t N, int64_t K, cons
       (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
   }
-  dev_free(dA); dev_free(dB); dev_free(dC);
+  dev_free(dA); if (!same) dev_free(dB);
+  dev_free(dC);
   return rc;
 }
 

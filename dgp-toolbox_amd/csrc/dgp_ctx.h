@@ -230,13 +230,15 @@ int G(dgp_ctx* ctx, int cat, GemmOp op, long M, long N, long K, const double* A,
   a.alpha = alpha; a.beta = beta; a.tri = tri; a.triblk = triblk;
   if (M <= 0 || N <= 0 || K <= 0) return DGP_OK;
   ProfScope ps(ctx, cat, flops, bytes);
-  HIPCHK(gemm_f64(ctx->st, op, a));
+  if (!a.gram_ws && ctx->gram_ws) { a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = gemm_gram_ws_bytes(); }   // (gemm_gram.h; only
+  HIPCHK(gemm_f64(ctx->st, op, a));                       //  reductions over >= 8192 points are eligible: never a chain product)
   return DGP_OK;
 }
 
 int GX(dgp_ctx* ctx, int cat, GemmOp op, GemmArgs a, double flops = 0.0, double bytes = 0.0) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return DGP_OK;
   ProfScope ps(ctx, cat, flops, bytes);
+  if (!a.gram_ws && ctx->gram_ws) { a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = gemm_gram_ws_bytes(); }
   HIPCHK(gemm_f64(ctx->st, op, a));
   return DGP_OK;
 }
@@ -537,7 +539,7 @@ int prep(dgp_ctx* ctx, bool train = false, bool overlap = false) {
                      train ? y.Euu : nullptr));
     if (y.off_white >= 0) HIPCHK(add_diag_dev(ctx->st, y.Kuu, M, Mp, P(ctx, y.off_white)));
     HIPCHK(copy_mat(ctx->st, y.Kuu, y.Lu, MM));
-    HIPCHK(potrf_inv(ctx->st, y.Lu, y.Linv, ctx->sm[9], Mp, 1, ctx->info));
+    HIPCHK(potrf_inv(ctx->st, y.Lu, y.Linv, ctx->sm[9], Mp, 1, ctx->info, M));
     HIPCHK(wcat_transpose(ctx->st, y.Linv, Mp, 1, y.LinvT));
     if (y.d.white) {
       HIPCHK(lq_to_wcat(ctx->st, y.Lq, Mp, D, y.Wcat));

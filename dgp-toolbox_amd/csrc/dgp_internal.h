@@ -37,7 +37,8 @@ constexpr double kLikVarLower = 1e-6;   // gpflow Gaussian variance lower bound 
 hipError_t rbf_kuu(hipStream_t st, int kind, const double* Z, const double* var, const double* ls, int M, int Mp, int Din,
                    double* Kuu /* + jitter*I, identity on the padding */, double* Euu /* e factors, or null */);
 // A <- chol(A) (lower, upper zeroed) and X <- A^-1 of the factor; tmp = scratch [batch x Mp x Mp]; info: device flag set on non-PD
-hipError_t potrf_inv(hipStream_t st, double* A, double* X, double* tmp, int Mp, int batch, int* info);
+hipError_t potrf_inv(hipStream_t st, double* A, double* X, double* tmp, int Mp, int batch, int* info,
+                     int n_act = 0 /* > 0: rows / columns >= n_act of A are an identity block (the padding of M up to Mp) */);
 hipError_t trinv_lower(hipStream_t st, const double* L, double* X, double* tmp, int Mp, int batch);
 // Lq[d] (padded, identity padding) <- tril(q_sqrt[d]) ; qmu_p (padded rows zero) <- q_mu
 hipError_t pack_q(hipStream_t st, const double* q_sqrt, const double* q_mu, int M, int Mp, int D, double* Lq,

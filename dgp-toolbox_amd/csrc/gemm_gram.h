@@ -255,6 +255,24 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
       w_static_for<0, U>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value, sub = u_sub(u), q = u_grp(u), ci = u_ci(u), ph = sub * NG + q;
         constexpr bool ph_start = ci == 0;
+        if constexpr (u % (SUBH * NS) == (SUBH / 2) * NS) {
+          constexpr int h = u / (SUBH * NS);
+          // (first in its unit: with one group per wave this unit also starts the stage's last phase, which reads the
+          //  NEXT stage's first A fragments - only published by this barrier)
+          // mid k-tile: this wave's pieces of the NEXT k-tile have landed (the one after it may stay in flight); the
+          // barrier publishes the next k-tile and certifies that every wave has left the PREVIOUS k-tile, whose stage
+          // takes the request for the k-tile three ahead.  (No LDS read has to be complete here: the current stage is
+          // not overwritten before the next barrier.)
+          __builtin_amdgcn_sched_barrier(0);
+          wait_tiles1();
+#ifndef GR_ABL_NOBAR
+          __builtin_amdgcn_s_barrier();
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+#ifndef GR_ABL_NODMA
+          issue_x(KH * i + h + 3, (stage + h + 3) & (GR_NSTAGE - 1));
+#endif
+        }
         if constexpr (ph_start) {
 #pragma unroll
           for (int ri = 0; ri < GM::m.nr[q]; ++ri) fa[ri] = SC ? fr[ri] * fw : fr[ri];
@@ -269,22 +287,6 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
           // (fence: left to itself the scheduler sinks these reads to the last LDS slots before their first use, which
           //  for the k-tile's last phase is the top of the next iteration)
           __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (u % (SUBH * NS) == (SUBH / 2) * NS) {
-          constexpr int h = u / (SUBH * NS);
-          // mid k-tile: this wave's pieces of the NEXT k-tile have landed (the one after it may stay in flight); the
-          // barrier publishes the next k-tile and certifies that every wave has left the PREVIOUS k-tile, whose stage
-          // takes the request for the k-tile three ahead.  (No LDS read has to be complete here: the current stage is
-          // not overwritten before the next barrier.)
-          __builtin_amdgcn_sched_barrier(0);
-          wait_tiles1();
-#ifndef GR_ABL_NOBAR
-          __builtin_amdgcn_s_barrier();
-#endif
-          __builtin_amdgcn_sched_barrier(0);
-#ifndef GR_ABL_NODMA
-          issue_x(KH * i + h + 3, (stage + h + 3) & (GR_NSTAGE - 1));
-#endif
         }
         if constexpr (u % (SUBH * NS) == SUBH * NS - 2) {
           // from here on the B fragment reads belong to the next stage

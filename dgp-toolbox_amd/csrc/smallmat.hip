@@ -61,20 +61,24 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// LF = 64: the leaf of the recursion.  LF = 32: models with at most 32 inducing points (the Bayesian-optimisation
+// surrogates; Mp = 64 with an identity padding): a quarter of the dependent readlane / fma chain (57 -> 16 us), the padding
+// rows [n, npad) of X are written as identity rows.
+template <int LF>
 __global__ __launch_bounds__(64) void leaf_potrf_inv_kernel(double* __restrict__ Aall, double* __restrict__ Xall, int ld,
                                                             long stride, int off, int n, int do_chol,
-                                                            int* __restrict__ info) {
-  __shared__ double T[LEAF][LEAF + 1];
+                                                            int* __restrict__ info, int npad) {
+  __shared__ double T[LF][LF + 1];
   double* A = Aall + (long)blockIdx.x * stride + (long)off * ld + off;
   double* X = Xall + (long)blockIdx.x * stride + (long)off * ld + off;
   const int i = threadIdx.x;
   for (int r = 0; r < n; ++r)
     if (i < n) T[r][i] = A[(long)r * ld + i];
   __syncthreads();
-  double a[LEAF];
+  double a[LF];
   // rows and columns beyond n behave as an identity block
 #pragma unroll
-  for (int j = 0; j < LEAF; ++j) {
+  for (int j = 0; j < LF; ++j) {
     const double v = T[i < n ? i : 0][j];
     a[j] = (i < n && j < n) ? (j <= i ? v : 0.0) : (i == j ? 1.0 : 0.0);
   }
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(64) void leaf_potrf_inv_kernel(double* __restrict__
   if (do_chol) {
     bool bad = false;
 #pragma unroll
-    for (int c = 0; c < LEAF; ++c) {
+    for (int c = 0; c < LF; ++c) {
       const double piv = lane_bcast(a[c], c);
       // 1/sqrt(pivot): hardware estimate + two Newton steps (a library sqrt and a division are ~40 dependent
       // fp64 operations on the critical path of every column)
@@ -94,40 +98,45 @@ __global__ __launch_bounds__(64) void leaf_potrf_inv_kernel(double* __restrict__
       a[c] = l;
       if (i == c) diag = l;
 #pragma unroll
-      for (int j = c + 1; j < LEAF; ++j) a[j] = fma(-l, lane_bcast(l, j), a[j]);   // only j <= i is meaningful
+      for (int j = c + 1; j < LF; ++j) a[j] = fma(-l, lane_bcast(l, j), a[j]);   // only j <= i is meaningful
     }
     if (bad && i == 0) atomicOr(info, 1);
     __syncthreads();
+    if (i < LF)
 #pragma unroll
-    for (int j = 0; j < LEAF; ++j) T[i][j] = a[j];
+      for (int j = 0; j < LF; ++j) T[i][j] = a[j];
     __syncthreads();
     for (int r = 0; r < n; ++r)
       if (i < n) A[(long)r * ld + i] = T[r][i];
   } else {
 #pragma unroll
-    for (int j = 0; j < LEAF; ++j) diag = (i == j) ? a[j] : diag;
+    for (int j = 0; j < LF; ++j) diag = (i == j) ? a[j] : diag;
   }
   const double dinv = 1.0 / diag;
 #pragma unroll
-  for (int k = 0; k < LEAF; ++k) a[k] = (i > k) ? a[k] * dinv : 0.0;      // strictly lower part of L' = D^-1 L
+  for (int k = 0; k < LF; ++k) a[k] = (i > k) ? a[k] * dinv : 0.0;      // strictly lower part of L' = D^-1 L
 #pragma unroll
-  for (int k = 0; k < LEAF; ++k) {
+  for (int k = 0; k < LF; ++k) {
     const double m = a[k];                                  // L'[i][k] for the rows below k, 0 for the others
 #pragma unroll
     for (int j = 0; j < k; ++j) a[j] = fma(-m, lane_bcast(a[j], k), a[j]);   // row k of X' is final in lane k
     a[k] = -m;
   }
 #pragma unroll
-  for (int j = 0; j < LEAF; ++j) {
+  for (int j = 0; j < LF; ++j) {
     const double dj = lane_bcast(dinv, j);
     a[j] = (i > j) ? a[j] * dj : (i == j ? dinv : 0.0);
   }
   __syncthreads();
+  if (i < LF)
 #pragma unroll
-  for (int j = 0; j < LEAF; ++j) T[i][j] = a[j];
+    for (int j = 0; j < LF; ++j) T[i][j] = a[j];
   __syncthreads();
   for (int r = 0; r < n; ++r)
     if (i < n) X[(long)r * ld + i] = T[r][i];
+  // identity padding of X (and zeros beside it) when the factorisation covers only the leading n of npad rows
+  for (int r = 0; r < npad; ++r)
+    if (i < npad && (r >= n || i >= n)) X[(long)r * ld + i] = (r == i) ? 1.0 : 0.0;
 }
 
 // batched strided block copy: dst[b][r][c] = src[b][r][c] for an nr x nc block (leading dimension ld, batch stride)
@@ -160,7 +169,7 @@ static hipError_t potrf_inv_rec(hipStream_t st, double* A, double* X, double* tm
                                 int n, int do_chol, int* info) {
   hipError_t e;
   if (n <= LEAF) {
-    hipLaunchKernelGGL(leaf_potrf_inv_kernel, dim3(batch), dim3(64), 0, st, A, X, ld, stride, off, n, do_chol, info);
+    hipLaunchKernelGGL(leaf_potrf_inv_kernel<LEAF>, dim3(batch), dim3(64), 0, st, A, X, ld, stride, off, n, do_chol, info, 0);
     return hipGetLastError();
   }
   int n1 = ((n / 2 + 15) / 16) * 16;
@@ -198,7 +207,11 @@ static hipError_t potrf_inv_rec(hipStream_t st, double* A, double* X, double* tm
   return hipGetLastError();
 }
 
-hipError_t potrf_inv(hipStream_t st, double* A, double* X, double* tmp, int Mp, int batch, int* info) {
+hipError_t potrf_inv(hipStream_t st, double* A, double* X, double* tmp, int Mp, int batch, int* info, int n_act) {
+  if (Mp <= LEAF && n_act > 0 && n_act <= 32) {      // A = blockdiag(A[:n, :n], I): only the leading block is factorised
+    hipLaunchKernelGGL(leaf_potrf_inv_kernel<32>, dim3(batch), dim3(64), 0, st, A, X, Mp, (long)Mp * Mp, 0, n_act, 1, info, Mp);
+    return hipGetLastError();
+  }
   return potrf_inv_rec(st, A, X, tmp, Mp, (long)Mp * Mp, batch, 0, Mp, 1, info);
 }
 

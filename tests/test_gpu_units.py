@@ -55,6 +55,28 @@ def test_gemm_split_k_atomic_accumulation(ctx):
     assert _rel(C, C0 + A.T @ B) < 1e-12
 
 
+@pytest.mark.parametrize("K", [8192, 20000, 70000 - 70000 % 16 + 16])
+def test_gram_kernel_reductions_over_the_points(ctx, K):
+    """The reductions over the points with a 256 x 256 lower-triangular output (G_d = Ct^T diag(v) Ct, Q = Kbar^T Ct;
+    SURVEY App. C step 2) run in the weighted Gram kernel (gemm_gram.h) from 8192 points on: the two-source form
+    (A != B) and the one-source form (the same operand twice) against NumPy, added to a pre-filled C; one point short of
+    a multiple of 16 the same call takes the 128 x 64 engine - same answer."""
+    rng = np.random.default_rng(K)
+    A = rng.standard_normal((K, 256)); B = rng.standard_normal((K, 256)); C0 = rng.standard_normal((256, 256))
+    lower = np.tril(np.ones((256, 256), dtype=bool))
+    for a, b in ((A, B), (A, A)):
+        want = C0 + a.T @ b
+        for k in (K, K - 1):
+            got = ctx.dev_gemm("TN", a[:k], a[:k] if b is a else b[:k], C0=C0, beta=1, splits=8, tri=3, triblk=256)
+            ref = C0 + a[:k].T @ (a[:k] if b is a else b[:k])
+            assert np.abs(got - ref)[lower].max() <= 1e-12 * np.abs(ref).max(), (k, b is a)
+        del want
+    # fixed summation order: the kernel has no atomics, two runs agree to the bit
+    g1 = ctx.dev_gemm("TN", A, A, C0=C0, beta=1, splits=8, tri=3, triblk=256)
+    g2 = ctx.dev_gemm("TN", A, A, C0=C0, beta=1, splits=8, tri=3, triblk=256)
+    assert np.array_equal(g1[lower], g2[lower])
+
+
 @pytest.mark.parametrize("Mp", [128, 256, 272])
 def test_gemm_triangular_hints_are_exact(ctx, Mp):
     """TRI_* only skip structurally-zero work: results equal the dense product."""
