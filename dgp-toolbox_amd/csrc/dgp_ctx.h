@@ -675,6 +675,9 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       a.tri = TRI_B_LOWER; a.triblk = Mp;
       if (y.d.kernel_kind != DGP_KERNEL_MF) {
         a.emul = y.Et ? y.Et : y.Kt; a.C2 = ctx->Gt;        // g = dK .* e (e = -2 dk/dr2; = k for the squared exponential)
+        // dK itself has one more reader, Q = dK^T C = Linv^T (Cbar^T C): that reduction takes Cbar instead (finish_layer
+        // applies Linv^T to the summed 256 x 256 result), so the stationary kernels never write dK: 2 GB per 10^6 points
+        a.c2_only = 1;
       }
       RET(GX(ctx, 0, GEMM_NN, a, tri1, (double)Pl * Mp * 32));
     }
@@ -688,7 +691,8 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       RET(GX(ctx, 0, GEMM_TN, a, tri1 * D, (double)Pl * Mp * 8));
     }
     {
-      GemmArgs a = mk(Mp, Mp, Pl, ctx->Kbar, Mp, y.Ct, Mp, acc + y.acc_Q, Mp, 1.0, 1);
+      // Q' = Cbar^T C (stationary kernels; Q = Linv^T Q' in finish_layer) or Q = dK^T C (composite kernel: dK is stored)
+      GemmArgs a = mk(Mp, Mp, Pl, y.d.kernel_kind != DGP_KERNEL_MF ? ctx->Cbar : ctx->Kbar, Mp, y.Ct, Mp, acc + y.acc_Q, Mp, 1.0, 1);
       a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp), Pl, (long)Mp * 16);
       a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = ctx->gram_ws ? gemm_gram_ws_bytes() : 0;     // (Mp = 256: gemm_gram.h, two sources)
       RET(GX(ctx, 0, GEMM_TN, a, tri1, (double)Pl * Mp * 16));

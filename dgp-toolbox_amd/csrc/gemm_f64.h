@@ -100,6 +100,7 @@ struct GemmArgs {
   // optional second output C2 = (alpha * A B) .* E  (same shape / leading dimension as C; used for g = dK .* K)
   const double* emul = nullptr;
   double* C2 = nullptr;
+  int c2_only = 0;     // 1: only C2 = C .* emul is stored, C itself is not (overwrite semantics only: beta = 0, splits = 1)
   double* gram_ws = nullptr;   // scratch for gemm_gram.h's partial triangles (gram_ws_bytes >= gemm_gram_ws_bytes())
   long gram_ws_bytes = 0;
   int no_wide = 0;     // 1: keep this product on the 128 x 64 engine even where the wide-tile kernel (gemm_wide.h) applies
@@ -674,8 +675,10 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
             *reinterpret_cast<d2_t*>(g.C2 + o) = v0 * *reinterpret_cast<const d2_t*>(g.emul + o);
             *reinterpret_cast<d2_t*>(g.C2 + o + 2) = v1 * *reinterpret_cast<const d2_t*>(g.emul + o + 2);
           }
-          *reinterpret_cast<d2_t*>(C + o) = v0;
-          *reinterpret_cast<d2_t*>(C + o + 2) = v1;
+          if (!g.c2_only) {
+            *reinterpret_cast<d2_t*>(C + o) = v0;
+            *reinterpret_cast<d2_t*>(C + o + 2) = v1;
+          }
         }
       continue;
     }
@@ -699,7 +702,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
           double* p = C + row * g.ldc + col;
           double v = acc[i][j][r];
           if (g.eadd != nullptr) v -= esc * g.eadd[row * g.ldc + col];
-          if (atomic) unsafeAtomicAdd(p, v);
+          if (g.c2_only) {}
+          else if (atomic) unsafeAtomicAdd(p, v);
           else if (g.beta) *p += v;
           else *p = v;
           if (g.C2 != nullptr) g.C2[row * g.ldc + col] = v * g.emul[row * g.ldc + col];
