@@ -225,6 +225,18 @@ __global__ __launch_bounds__(256) void finalize_layer_rows_kernel(
   }
 }
 
+// F[s][p][d] = mean[p][d] + z sqrt(var[p][d] + jitter) for the S samples of the first layer's points, one thread per value
+__global__ __launch_bounds__(256) void expand_f_kernel(const double* __restrict__ mean, const double* __restrict__ var, long Nc,
+                                                       int S, int D, ZSource zsrc, long n_chunk0, double* __restrict__ F) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nd = Nc * D;
+  if (idx >= (long)S * nd) return;
+  const int s = (int)(idx / nd);
+  const long r = idx - (long)s * nd, p = r / D;
+  const int d = (int)(r - p * D);
+  F[idx] = mean[r] + draw_z(zsrc, s, n_chunk0 + p, d, D) * sqrt(var[r] + kJitter);
+}
+
 hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, int nplane, long pstride,
                           const double* mean0,
                           const double* Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
@@ -232,15 +244,22 @@ hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, 
                           long n_chunk0, double* mean, double* var, double* F, int kernel_kind, const double* white) {
   const long n = P * D;
   if (n == 0) return hipSuccess;
-  if (P >= 400000 && D > 1) {
+  // first layer with many samples (the acquisition side draws S = 1000 samples of a handful of candidates): the kernels
+  // above would walk the S samples of a point in one thread (0.75 ms for one candidate) - they leave F to expand_f_kernel
+  const bool wide_s = dedup && F != nullptr && S > 16;
+  double* Fk = wide_s ? nullptr : F;
+  if (P >= 400000 && D > 1)
     hipLaunchKernelGGL(finalize_layer_rows_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, cnp, tnp, nplane, pstride,
-                       mean0, Xin, x_row0, P, Nc, S, dedup, Din, D, kvar, mean_kind, meanW, meanb, zsrc, n_chunk0, mean, var, F,
+                       mean0, Xin, x_row0, P, Nc, S, dedup, Din, D, kvar, mean_kind, meanW, meanb, zsrc, n_chunk0, mean, var, Fk,
                        kernel_kind, white);
-    LAUNCH_CHECK();
+  else
+    hipLaunchKernelGGL(finalize_layer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cnp, tnp, nplane, pstride, mean0,
+                       Xin, x_row0, P, Nc, S, dedup, Din, D, kvar, mean_kind, meanW, meanb, zsrc, n_chunk0, mean, var, Fk,
+                       kernel_kind, white);
+  if (wide_s) {
+    const long tot = (long)S * Nc * D;
+    hipLaunchKernelGGL(expand_f_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, mean, var, Nc, S, D, zsrc, n_chunk0, F);
   }
-  hipLaunchKernelGGL(finalize_layer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cnp, tnp, nplane, pstride, mean0, Xin,
-                     x_row0, P, Nc, S, dedup, Din, D, kvar, mean_kind, meanW, meanb, zsrc, n_chunk0, mean, var, F, kernel_kind,
-                     white);
   LAUNCH_CHECK();
 }
 
@@ -329,10 +348,43 @@ __global__ __launch_bounds__(256) void fold_kernel(const double* __restrict__ Fb
   if (acc_dkvar) block_atomic_add(dk, acc_dkvar, sh);
 }
 
+// The first layer's fold with many samples: one wave per (point, output) strides over the S samples (the loop above
+// in one thread took 0.8 ms for one candidate at S = 1000).
+__global__ __launch_bounds__(256) void fold_dedup_wide_kernel(const double* __restrict__ Fbar, const double* __restrict__ var,
+                                                              long Nc, int S, int D, ZSource zsrc, long n_chunk0,
+                                                              double* __restrict__ mbar, double* __restrict__ vbar,
+                                                              double* __restrict__ acc_dkvar) {
+  __shared__ double sh[4];
+  const long pd = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  double vb = 0.0;
+  if (pd < Nc * D) {
+    const long p = pd / D;
+    const int d = (int)(pd - p * D);
+    const double inv = 0.5 / sqrt(var[pd] + kJitter);
+    double mb = 0.0;
+    for (int s = lane; s < S; s += 64) {
+      const double fb = Fbar[((long)s * Nc + p) * D + d];
+      mb += fb;
+      vb += fb * draw_z(zsrc, s, n_chunk0 + p, d, D) * inv;
+    }
+    mb = wave_sum(mb);
+    vb = wave_sum(vb);
+    if (lane == 0) { mbar[pd] = mb; vbar[pd] = vb; }
+    if (lane != 0) vb = 0.0;
+  }
+  if (acc_dkvar) block_atomic_add(vb, acc_dkvar, sh);
+}
+
 hipError_t fold_sample_grad(hipStream_t st, const double* Fbar, const double* var, long Nc, int S, int dedup, int D,
                             ZSource zsrc, long n_chunk0, double* mbar, double* vbar, double* acc_dkvar) {
   const long total = (dedup ? Nc : (long)S * Nc) * D;
   if (total == 0) return hipSuccess;
+  if (dedup && S > 16) {
+    hipLaunchKernelGGL(fold_dedup_wide_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, Fbar, var, Nc, S, D, zsrc,
+                       n_chunk0, mbar, vbar, acc_dkvar);
+    LAUNCH_CHECK();
+  }
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Fbar, var, Nc, S, dedup, D, zsrc, n_chunk0,

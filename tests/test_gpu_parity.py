@@ -673,6 +673,36 @@ def test_propagate_vjp_matches_autograd(case):
     _close(got2, want, rtol=0, atol=1e-8 * np.abs(want).max())
 
 
+def test_propagate_and_vjp_with_many_samples_of_few_points():
+    """The acquisition side evaluates S = 1000 samples of a handful of candidates (Infill_criteria.py:60-85): from 17
+    samples on the first layer's sampling and its fold over the samples run one thread per value / one wave per
+    (point, output) instead of a per-thread loop over S (points.hip).  Same parity as the small-S cases: injected
+    normals, torch autograd on the oracle."""
+    import dgp_oracle_torch as OT
+    g = load(CASES[0])
+    m = product_from_golden(g)
+    om = oracle_from_golden(g)
+    nl = n_layers(g)
+    Xn = g["Xnew"][:3]
+    S = 40
+    rng = np.random.default_rng(17)
+    douts = [g[f"znew{i}"].shape[2] for i in range(nl)]
+    zn = [rng.standard_normal((S, Xn.shape[0], d)) for d in douts]
+    shp = (S, Xn.shape[0], douts[-1])
+    fb, mb, vb = (rng.standard_normal(shp) for _ in range(3))
+    want, F, Fm, Fv = OT.propagate_vjp(om, Xn, zn, S, fb, mb, vb)
+    Fs_g, Fm_g, Fv_g = m.propagate(Xn, S=S, zs=zn)
+    for got_l, want_l in ((Fs_g[-1], F), (Fm_g[-1], Fm), (Fv_g[-1], Fv)):
+        _close(np.asarray(got_l).reshape(-1), np.asarray(want_l).reshape(-1), rtol=1e-9, atol=1e-9)
+    got = m.propagate_vjp(Xn, S=S, f_bar=fb, mean_bar=mb, var_bar=vb, zs=zn)
+    _close(got, want, rtol=0, atol=1e-8 * np.abs(want).max())
+    # Philox normals: the value does not depend on how the samples are spread over threads (replay with the same seed)
+    ctx = m._sync_model()
+    a = ctx.propagate(Xn, S, 5, None)
+    b = ctx.propagate(Xn, S, 5, None)
+    assert np.array_equal(np.asarray(a[0][-1]), np.asarray(b[0][-1]))
+
+
 def test_propagate_vjp_philox_replay_and_finite_difference():
     """With device-drawn normals the VJP must differentiate the SAME draws as the forward call (seed replay):
     checked by central finite differences of predict_f's moment-matched mean/variance along a random direction."""
