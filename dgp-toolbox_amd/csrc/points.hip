@@ -427,11 +427,49 @@ __global__ __launch_bounds__(256) void vjp_seed_kernel(const double* __restrict_
   }
   if (acc_dkvar) block_atomic_add(dk, acc_dkvar, sh);
 }
+// single-layer model with many samples: one wave per (point, output) strides over the S samples (as fold_dedup_wide_kernel)
+__global__ __launch_bounds__(256) void vjp_seed_dedup_wide_kernel(const double* __restrict__ fbar, const double* __restrict__ meanbar,
+                                                                  const double* __restrict__ varbar, const double* __restrict__ var,
+                                                                  long Nc, int S, int D, ZSource zsrc, long Ntot, long n_chunk0,
+                                                                  double* __restrict__ mbar, double* __restrict__ vbar,
+                                                                  double* __restrict__ acc_dkvar) {
+  __shared__ double sh[4];
+  const long pd = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  double vb = 0.0;
+  if (pd < Nc * D) {
+    const long p = pd / D;
+    const int d = (int)(pd - p * D);
+    const double inv = 0.5 / sqrt(var[pd] + kJitter);
+    double mb = 0.0;
+    for (int s = lane; s < S; s += 64) {
+      const long src = ((long)s * Ntot + n_chunk0 + p) * D + d;
+      if (meanbar) mb += meanbar[src];
+      if (varbar) vb += varbar[src];
+      if (fbar) {
+        const double fb = fbar[src];
+        mb += fb;
+        vb += fb * draw_z(zsrc, s, n_chunk0 + p, d, D) * inv;
+      }
+    }
+    mb = wave_sum(mb);
+    vb = wave_sum(vb);
+    if (lane == 0) { mbar[pd] = mb; vbar[pd] = vb; }
+    if (lane != 0) vb = 0.0;
+  }
+  if (acc_dkvar) block_atomic_add(vb, acc_dkvar, sh);
+}
+
 hipError_t vjp_seed(hipStream_t st, const double* fbar, const double* meanbar, const double* varbar, const double* var,
                     long Nc, int S, int dedup, int D, ZSource zsrc, long Ntot, long n_chunk0, double* mbar, double* vbar,
                     double* acc_dkvar) {
   const long total = (dedup ? Nc : (long)S * Nc) * D;
   if (total == 0) return hipSuccess;
+  if (dedup && S > 16) {
+    hipLaunchKernelGGL(vjp_seed_dedup_wide_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, fbar, meanbar, varbar, var, Nc,
+                       S, D, zsrc, Ntot, n_chunk0, mbar, vbar, acc_dkvar);
+    LAUNCH_CHECK();
+  }
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(vjp_seed_kernel, dim3((unsigned)blocks), dim3(256), 0, st, fbar, meanbar, varbar, var, Nc, S, dedup, D,

@@ -748,12 +748,13 @@ def test_propagate_vjp_single_layer_model():
     q = rng.standard_normal((12, 1)) * 0.3
     m.layers[0].q_mu.assign(q)
     om.layers[0].q_mu = q.copy()
-    S, Xn = 4, rng.uniform(-1, 1, (9, 3))
-    zn = [rng.standard_normal((S, 9, 1))]
-    fb, mb, vb = (rng.standard_normal((S, 9, 1)) for _ in range(3))
-    want, *_ = OT.propagate_vjp(om, Xn, zn, S, fb, mb, vb)
-    got = m.propagate_vjp(Xn, S=S, f_bar=fb, mean_bar=mb, var_bar=vb, zs=zn)
-    _close(got, want, rtol=0, atol=1e-9 * np.abs(want).max())
+    Xn = rng.uniform(-1, 1, (9, 3))
+    for S in (4, 70):            # 70: the many-samples form of the seed kernel (one wave per point and output, S > 16)
+        zn = [rng.standard_normal((S, 9, 1))]
+        fb, mb, vb = (rng.standard_normal((S, 9, 1)) for _ in range(3))
+        want, *_ = OT.propagate_vjp(om, Xn, zn, S, fb, mb, vb)
+        got = m.propagate_vjp(Xn, S=S, f_bar=fb, mean_bar=mb, var_bar=vb, zs=zn)
+        _close(got, want, rtol=0, atol=1e-9 * np.abs(want).max())
 
 
 def _pin(m, seed):
