@@ -311,8 +311,11 @@ int pick_splits_tiles(dgp_ctx* ctx, long active_tiles, long K, long row_bytes = 
   const long fill = (2L * (ctx->cu_count > 0 ? ctx->cu_count : 256) + active_tiles - 1) / (active_tiles > 0 ? active_tiles : 1);
   // small models (one or two output tiles: M <= 128 inducing points, the Bayesian-optimisation surrogates): the whole
   // reduction over the points ran on 8 workgroups and was half of the iteration (4 launches of 100-145 us at N = 1000,
-  // S = 10); 256 rows per split keep the atomics of a split (one 128 x 64 tile) below its MFMA work
-  if (active_tiles <= 16 && min_rows > 256) min_rows = 256;
+  // S = 10); 128 rows per split: the k-tiles of a split are a dependent chain of global-load latencies, its atomics one
+  // 128 x 64 tile (measured at config 1: 64 rows 0.70 ms, 128: 0.69, 256: 0.73, 512: 0.76, 1024: 1.00 per iteration)
+  static long small_rows = 0;
+  if (small_rows == 0) { const char* e = getenv("DGP_SMALL_SPLIT_ROWS"); small_rows = e ? atol(e) : 128; if (small_rows < 16) small_rows = 16; }
+  if (active_tiles <= 16 && min_rows > small_rows) min_rows = small_rows;
   const long cap = K / min_rows;
   if (s < fill) s = fill < cap ? fill : cap;
   s = ((s + 7) / 8) * 8;
