@@ -42,6 +42,9 @@ namespace dgp {
 #ifndef GR_ASM_MFMA
 #define GR_ASM_MFMA 1
 #endif
+#ifndef GR_AHEAD
+#define GR_AHEAD 2      // B fragments are read this many units ahead of their MFMAs (ring of four slots: 2 or 3; 3 measured: no change)
+#endif
 
 constexpr int GR_STAGE_B = 16 * 256 * 8;        // 32 KB: [16 k][128 chunks of 16 B], chunk ^ ((k >> 1) & 1)
 constexpr int GR_STAGE_S = 2048;                // 16 points x up to 8 weights (1 KB) + spare
@@ -246,6 +249,9 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
     rawA(std::integral_constant<int, 0>{});
     readB(0, uoff(0));
     readB(1, uoff(1));
+#if GR_AHEAD == 3
+    readB(2, uoff(2));
+#endif
 
     for (int i = 0; i < nkt; ++i) {
       // address step out of the stage of half 0 / half 1 of this iteration
@@ -288,11 +294,11 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
           //  for the k-tile's last phase is the top of the next iteration)
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (u % (SUBH * NS) == SUBH * NS - 2) {
+        if constexpr (u % (SUBH * NS) == SUBH * NS - GR_AHEAD) {
           // from here on the B fragment reads belong to the next stage
           { const int ds = (u / (SUBH * NS)) == 0 ? dstep0 : dstep1; bB0 += ds; bB1 += ds; }
         }
-        readB((u + 2) & 3, uoff((u + 2) % U));
+        readB((u + GR_AHEAD) & 3, uoff((u + GR_AHEAD) % U));
         w_static_for<0, GM::m.nr[q]>([&](auto rc) __attribute__((always_inline)) {
           constexpr int ri = decltype(rc)::value;
           if constexpr ((GM::m.mask[q][ci] >> ri) & 1u) {
