@@ -205,7 +205,10 @@ int dgp_prof_enable(dgp_ctx* ctx, int32_t on);
 int dgp_prof_read(dgp_ctx* ctx, int32_t n_cat, double* ms_out, int64_t* launches_out, double* alg_flops_out,
                   double* alg_bytes_out);   /* synchronises, returns totals since enable, then resets */
 
-/* ---- unit-level entry points (used by tests/ to check single kernels against NumPy) ------------- */
+/* ---- unit-level entry points (used by tests/ to check single kernels against NumPy) -------------
+ * dgp_dev_gemm: C = alpha op(A) op(B) (+ C if beta) on the engine the shapes select (128 x 64 engine, wide-tile kernel,
+ * weighted Gram kernel).  The same host pointer for A and B (equal shapes) is uploaded ONCE and used as both operands:
+ * the one-source Gram form  C += A^T A  (tri = 3, M = N = 256, K a multiple of 16 >= 8192). */
 int dgp_dev_gemm(dgp_ctx* ctx, int32_t op /*0 NN,1 NT,2 TN*/, int64_t M, int64_t N, int64_t K, const double* A,
                  int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha, int32_t beta,
                  int32_t splits, int32_t tri, int64_t triblk, int32_t repeats, double* ms_per_call);
