@@ -1119,13 +1119,17 @@ def test_so_bo_constrained_run_on_the_notebook_problem(capsys):
     assert bo.model_C[0].data[0].shape[0] == 6            # the second iteration re-fed the grown data set
 
 
-def test_bench_py_multi_rank_launch_over_gloo(tmp_path):
+@pytest.mark.parametrize("shape", [("4000", "64", "4", "4"), ("4000", "256", "8", "8")])
+def test_bench_py_multi_rank_launch_over_gloo(tmp_path, shape):
     """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per process, barrier +
     max-over-ranks timing, one JSON line from rank 0), with two ranks sharing this GPU over gloo instead of RCCL:
-    the JSON contract must hold and the ELBO must equal the single-process run on the same (small) workload."""
+    the JSON contract must hold and the ELBO must equal the single-process run on the same (small) workload.  The second
+    shape (M = 256, 16 000 sample-points per rank) puts each rank's reductions over its points on the weighted Gram kernel
+    (G_d and Q' = Cbar^T C, whose all-reduced sum the finish chain turns into Q): the third iteration's ELBO depends on
+    two Adam steps with those gradients."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    args = ["--N", "4000", "--M", "64", "--S", "4", "--num-units", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    args = ["--N", shape[0], "--M", shape[1], "--S", shape[2], "--num-units", shape[3], "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     port = 29700 + (os.getpid() % 2000)
     env = dict(os.environ, DGP_BENCH_BACKEND="gloo")
     cmd2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
