@@ -1019,6 +1019,32 @@ int dgp_dev_gemm(dgp_ctx* ctx, int32_t op, int64_t M, int64_t N, int64_t K, cons
   return rc;
 }
 
+int dgp_dev_gram(dgp_ctx* ctx, const double* C, const double* s, int64_t Pn, int32_t D, double* G) {
+  if (!ctx || !C || !G || Pn <= 0 || D < 1 || D > 64 || (!s && D != 1)) return fail(ctx, DGP_ERR_INVALID, "dgp_dev_gram: bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int Mp = 256;
+  const long MM = (long)Mp * Mp;
+  double *dC = nullptr, *ds = nullptr, *dG = nullptr;
+  RET(dev_alloc(ctx, &dC, (size_t)Pn * Mp));
+  RET(dev_alloc(ctx, &dG, (size_t)D * MM));
+  if (s) RET(dev_alloc(ctx, &ds, (size_t)Pn * D));
+  if (!ctx->gram_ws) RET(dev_alloc(ctx, &ctx->gram_ws, gemm_gram_ws_bytes() / 8));
+  HIPCHK(hipMemcpy(dC, C, (size_t)Pn * Mp * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dG, G, (size_t)D * MM * 8, hipMemcpyHostToDevice));
+  if (s) HIPCHK(hipMemcpy(ds, s, (size_t)Pn * D * 8, hipMemcpyHostToDevice));
+  // the call forward_chunk's backward makes (dgp_ctx.h: G_d)
+  GemmArgs a = mk(Mp, Mp, Pn, dC, Mp, dC, Mp, dG, Mp, 1.0, 1);
+  a.batch = D; a.sC = MM; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp) * D, Pn, (long)Mp * 8);
+  if (s) { a.ascale = ds; a.as_ld = D; a.ascale_mode = 2; }
+  int rc = GX(ctx, 0, GEMM_TN, a);
+  if (rc == DGP_OK) {
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipMemcpy(G, dG, (size_t)D * MM * 8, hipMemcpyDeviceToHost));
+  }
+  dev_free(dC); dev_free(dG); dev_free(ds);
+  return rc;
+}
+
 int dgp_dev_chol(dgp_ctx* ctx, double* A, int32_t M, int32_t batch) {
   if (!ctx || !A || M <= 0 || M % 16 != 0 || batch <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_dev_chol: M must be a multiple of 16");
   double* d;

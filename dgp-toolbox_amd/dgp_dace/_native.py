@@ -23,7 +23,7 @@ SYMBOLS = [
     "dgp_propagate_vjp", "dgp_vjp_accumulate", "dgp_propagate_full_cov", "dgp_gpr_lml", "dgp_gpr_predict", "dgp_gpr_predict_vjp",
     "dgp_grad_partial", "dgp_acc_info", "dgp_acc_bind", "dgp_grad_finish", "dgp_grad_get", "dgp_last_elbo", "dgp_grad_step",
     "dgp_comm_unique_id", "dgp_comm_init", "dgp_comm_destroy", "dgp_comm_allreduce",
-    "dgp_adam_reset", "dgp_adam_step", "dgp_adam_iterations", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_dev_gemm",
+    "dgp_adam_reset", "dgp_adam_step", "dgp_adam_iterations", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_dev_gemm", "dgp_dev_gram",
     "dgp_dev_chol", "dgp_dev_trinv", "dgp_dev_normals", "dgp_dev_mfma_peak",
 ]
 
@@ -103,6 +103,7 @@ def load():
         "dgp_prof_enable": (C.c_int, [vp, i32]),
         "dgp_prof_read": (C.c_int, [vp, i32, _dp, C.POINTER(i64), _dp, _dp]),
         "dgp_dev_gemm": (C.c_int, [vp, i32, i64, i64, i64, _dp, i64, _dp, i64, _dp, i64, dbl, i32, i32, i32, i64, i32, _dp]),
+        "dgp_dev_gram": (C.c_int, [vp, _dp, _dp, i64, i32, _dp]),
         "dgp_dev_chol": (C.c_int, [vp, _dp, i32, i32]),
         "dgp_dev_trinv": (C.c_int, [vp, _dp, _dp, i32, i32]),
         "dgp_dev_normals": (C.c_int, [vp, u64, i32, i32, i64, i64, i32, _dp]),
@@ -422,6 +423,15 @@ class Context:
         self._chk(self._lib.dgp_dev_gemm(self._h, opi, M, N, K, _ptr(A), A.shape[1], _ptr(B), B.shape[1], _ptr(Cm), N,
                                          alpha, beta, splits, tri, triblk, repeats, C.byref(ms)))
         return (Cm, ms.value) if repeats else Cm
+
+    def dev_gram(self, Cmat, s=None, G0=None):
+        """G[d] (+)= sum_p s[p, d] c_p c_p^T (lower triangles) by the library's dispatcher: Cmat [P, 256], s [P, D] or None."""
+        Cmat = _c(Cmat)
+        D = 1 if s is None else s.shape[1]
+        G = np.zeros((D, 256, 256)) if G0 is None else _c(G0).copy()
+        sp = None if s is None else _c(s)
+        self._chk(self._lib.dgp_dev_gram(self._h, _ptr(Cmat), None if sp is None else _ptr(sp), Cmat.shape[0], D, _ptr(G)))
+        return G
 
     def dev_chol(self, A):
         A = _c(A).copy()

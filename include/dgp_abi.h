@@ -212,6 +212,11 @@ int dgp_prof_read(dgp_ctx* ctx, int32_t n_cat, double* ms_out, int64_t* launches
 int dgp_dev_gemm(dgp_ctx* ctx, int32_t op /*0 NN,1 NT,2 TN*/, int64_t M, int64_t N, int64_t K, const double* A,
                  int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double alpha, int32_t beta,
                  int32_t splits, int32_t tri, int64_t triblk, int32_t repeats, double* ms_per_call);
+/* G[d] += sum_p s[p][d] c_p c_p^T (lower triangles; s == NULL: weights 1, D = 1) through the library's dispatcher, i.e.
+ * the weighted Gram kernel when eligible (Mp = 256, P a multiple of 16 >= 8192, D <= 8), else the 128 x 64 engine:
+ * the reduction  G_d = sum_p vbar_pd c_p c_p^T  of SURVEY App. C step 2 on its own. */
+int dgp_dev_gram(dgp_ctx* ctx, const double* C /* [P,256] */, const double* s /* [P,D] or NULL */, int64_t P, int32_t D,
+                 double* G /* [D,256,256], in/out */);
 int dgp_dev_chol(dgp_ctx* ctx, double* A, int32_t M, int32_t batch);            /* in place, lower */
 int dgp_dev_trinv(dgp_ctx* ctx, const double* L, double* X, int32_t M, int32_t batch);
 int dgp_dev_normals(dgp_ctx* ctx, uint64_t seed, int32_t layer, int32_t S, int64_t n0, int64_t N, int32_t D,

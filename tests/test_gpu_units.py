@@ -77,6 +77,24 @@ def test_gram_kernel_reductions_over_the_points(ctx, K):
     assert np.array_equal(g1[lower], g2[lower])
 
 
+@pytest.mark.parametrize("P,D", [(8192, 1), (8192 + 48, 8), (30000 - 30000 % 16, 3), (65536 + 16, 8), (20000, 5), (4096, 8), (10001, 2)])
+def test_weighted_gram_kernel_against_numpy(ctx, P, D):
+    """G_d += sum_p s[p, d] c_p c_p^T exactly as the backward pass calls it: on the weighted Gram
+    kernel for >= 8192 points in multiples of 16, on the 128 x 64 engine otherwise (4096 points; 10 001 points) - lower
+    triangles against NumPy, added to a pre-filled G, signed weights."""
+    rng = np.random.default_rng(P + D)
+    Cm = rng.standard_normal((P, 256)); s = rng.standard_normal((P, D)); G0 = rng.standard_normal((D, 256, 256))
+    got = ctx.dev_gram(Cm, s, G0)
+    lower = np.tril(np.ones((256, 256), dtype=bool))
+    for d in range(D):
+        ref = G0[d] + (Cm * s[:, d:d + 1]).T @ Cm
+        assert np.abs(got[d] - ref)[lower].max() <= 1e-12 * np.abs(ref).max(), d
+    if D == 1:
+        g1 = ctx.dev_gram(Cm, None, G0)
+        ref = G0[0] + Cm.T @ Cm
+        assert np.abs(g1[0] - ref)[lower].max() <= 1e-12 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("Mp", [128, 256, 272])
 def test_gemm_triangular_hints_are_exact(ctx, Mp):
     """TRI_* only skip structurally-zero work: results equal the dense product."""
