@@ -316,12 +316,12 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
             }
           }
         });
-        // issue order inside the unit: its first MFMA (it carries the wait for the fragments), then one LDS read per MFMA
-        constexpr int nm = 4 * gr_popc(GM::m.mask[q][ci]);
 #if GR_ASM_MFMA
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);      // (units stay in program order: fragment reads, then the unit's MFMAs)
 #else
         {
+          // issue order inside the unit: its first MFMA (it carries the wait for the fragments), then one LDS read per MFMA
+          constexpr int nm = 4 * gr_popc(GM::m.mask[q][ci]);
           constexpr int n_ds = 2;
           constexpr int n_vm = (u % (SUBH * NS) == (SUBH / 2) * NS) ? 4 : 0;                 // (the fifth request of waves 0 / 1 floats)
           constexpr int n_il = n_ds + n_vm < nm - 1 ? n_ds + n_vm : nm - 1;
