@@ -724,6 +724,9 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 // Host-side dispatcher (defined in gemm_f64.hip)
 enum GemmOp : int { GEMM_NN = 0, GEMM_NT = 1, GEMM_TN = 2 };
 hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args);
+// tall-tile kernel for the forward T product (gemm_tall.h / gemm_tall.hip)
+bool gemm_tall_ok(const GemmArgs& a);
+hipError_t gemm_tall(hipStream_t st, const GemmArgs& a);
 // weighted Gram products over the points (gemm_gram.h / gemm_gram.hip)
 bool gemm_gram_ok(const GemmArgs& a);
 long gemm_gram_ws_bytes();

@@ -1264,3 +1264,45 @@ def test_full_cov_beyond_1024_points():
         _close(Fs[i], oFs[i], rtol=1e-5, atol=1e-6)
     _, _, Fv_d = m.propagate(Xn, S=S, zs=zn)
     _close(np.einsum("siid->sid", np.asarray(Fv[0])), Fv_d[0], rtol=1e-8, atol=1e-10)
+
+
+TALL_WORKER = r'''
+import sys, io, contextlib, hashlib
+import numpy as np
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/dgp-toolbox_amd")
+from bench import synthetic
+from dgp_dace.gpflow_compat import RBF, Gaussian
+from dgp_dace.models.dgp import DGP
+N, D, M, S = 4096, 8, 256, 10
+X, Y, Z = synthetic(N, D, M)
+with contextlib.redirect_stdout(io.StringIO()):
+    m = DGP(X, Y, Z, [RBF(1.0, [1.0] * D) for _ in range(3)], [8, 8], Gaussian(), num_samples=S)
+ctx = m._sync_model()
+m._sync_data(m.data)
+ctx.grad_partial(S, 5, None)
+e = ctx.grad_finish(want_elbo=True)
+g = ctx.grad_get()
+np.savez(OUT, elbo=e, grad=g)
+'''
+
+
+def test_tall_tile_kernel_against_the_wide_tile_kernel(tmp_path):
+    """The forward product t_d = W_d^T c (all D output blocks of a 256-row tile, gemm_tall.h) adds the same k-tiles in
+    the same order as the wide-tile kernel it replaces (T itself is bit-identical, tools/wide_bench); only the partial
+    row sums |t_d|^2 are added in another order.  ELBO and gradient of a config-2-shaped model (M = 256, D = 8, 40960
+    sample points) must therefore agree to rounding between DGP_TALL=1 (default) and DGP_TALL=0.  The switches are read
+    once per process, hence the two child processes (one after the other)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"tall{flag}.npz")
+        code = f"ROOT={root!r}\nOUT={out!r}\n" + TALL_WORKER
+        env = dict(os.environ, DGP_TALL=flag)
+        p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           timeout=600)
+        assert p.returncode == 0, p.stdout
+        res.append(np.load(out))
+    assert abs(float(res[0]["elbo"]) - float(res[1]["elbo"])) < 1e-13 * abs(float(res[1]["elbo"]))
+    np.testing.assert_allclose(res[0]["grad"], res[1]["grad"], rtol=0, atol=1e-12 * np.abs(res[1]["grad"]).max())
+    assert np.isfinite(res[0]["grad"]).all() and np.abs(res[0]["grad"]).max() > 0
