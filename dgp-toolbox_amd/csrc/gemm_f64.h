@@ -727,6 +727,9 @@ hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args);
 // tall-tile kernel for the forward T product (gemm_tall.h / gemm_tall.hip)
 bool gemm_tall_ok(const GemmArgs& a);
 hipError_t gemm_tall(hipStream_t st, const GemmArgs& a);
+// tall-tile kernel for the backward dC product (gemm_tallu.h / gemm_tallu.hip)
+bool gemm_tallu_ok(const GemmArgs& a);
+hipError_t gemm_tallu(hipStream_t st, const GemmArgs& a);
 // weighted Gram products over the points (gemm_gram.h / gemm_gram.hip)
 bool gemm_gram_ok(const GemmArgs& a);
 long gemm_gram_ws_bytes();

@@ -166,6 +166,7 @@ hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args) {
   if (a.batch < 1) a.batch = 1;
   // row-panel products with a (block-)triangular or dense Mp-wide B: the wide-tile kernel
   if (op == GEMM_NN && !a.no_wide && gemm_tall_ok(a)) return gemm_tall(st, a);      // T = Ct * Wcat at Mp = 256: 256 x 128 tiles
+  if (op == GEMM_NN && !a.no_wide && gemm_tallu_ok(a)) return gemm_tallu(st, a);    // dC = [2 vbar .* T] * W^T ... at Mp = 256, likewise
   if (op == GEMM_NN && !a.no_wide && gemm_wide_ok(a)) return gemm_wide(st, a);
   // weighted Gram products over the points (lower triangle, Mp = 256): the single-staging kernel of gemm_gram.h
   if (op == GEMM_TN && !a.no_wide && gemm_gram_ok(a)) return gemm_gram(st, a);

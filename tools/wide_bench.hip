@@ -137,6 +137,8 @@ int main(int argc, char** argv) {
           a.sA = a.sB = a.sC = 0; a.batch = 1; a.splits = 1; a.ksplit = 0; a.alpha = 2.0; a.beta = 0;
           a.tri = TRI_B_UPPER; a.triblk = Mp; a.ascale = vbar; a.as_ld = D; a.a_kblk = Mp; a.ascale_mode = 1; a.a_wrap = 0;
           a.a_blocked = 1; a.eadd = Ct; a.eadd_nsc = D; a.rowf = mbar; a.colf = u; a.rank = D;
+          if (getenv("WB_NORANK")) { a.rank = 0; a.rowf = a.colf = nullptr; }
+          if (getenv("WB_NOEADD")) { a.eadd = nullptr; a.eadd_nsc = 0; }
           c.a = a; c.c_elems = (size_t)Pm * Mp; c.rs_elems = 0; c.alg_flops = tri1 * D; cases.push_back(c);
         }
         {  // dK = dC * Linv, g = dK .* k
