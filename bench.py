@@ -196,7 +196,7 @@ def main():
                        "parallelism": f"data points sharded over {world} GPU(s), one all-reduce per layer and iteration, overlapped with the backward pass"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_gram_kernel + dgp::gemm_f64_kernel (all point contractions, rank 0)",
+                         "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_tallu_kernel + dgp::gemm_gram_kernel + dgp::gemm_f64_kernel (all point contractions, rank 0)",
                          "kernel_ms_per_step": mf["ms"] / args.steps, "launches_per_step": mf["launches"] / args.steps,
                          "alg_flops_per_step_rank0": mf["alg_flops"] / args.steps,
                          "whole_step_frac": alg_flops_step(args.minibatch or args.N, args.S, dims, args.M, 1) / world / (dt / args.steps)

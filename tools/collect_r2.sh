@@ -20,6 +20,7 @@ timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/stats_bench.json 2>/dev/null || { echo "stats failed"; exit 1; }
 cd $R
 python tools/summarize_r2.py $O $O/summary || { echo "summarize failed"; exit 1; }
+python tools/iter_timeline.py $(find $O/stats -name '*kernel_trace.csv' | head -1) > $O/summary/r2_iteration_timeline.txt 2>&1 || echo "timeline failed"
 # the bench line proper reads the traffic figure measured just above
 DGP_TRAFFIC_JSON=$O/summary/r2_pmc_traffic.json timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err || { echo "bench failed"; tail -5 $O/bench.err; exit 1; }
 cat $O/bench.json

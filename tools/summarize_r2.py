@@ -48,7 +48,7 @@ for name, table, calls in (("fetch", fetch, fcalls), ("write", write, wcalls)):
         for k in sorted(table, key=table.get, reverse=True):
             w.writerow([k, calls[k], f"{table[k]:.3f}"])
 
-gemm = [k for k in fetch if "gemm_f64_kernel" in k or "gemm_wide_kernel" in k or "gemm_tall_kernel" in k or "gemm_gram_kernel" in k]
+gemm = [k for k in fetch if "gemm_f64_kernel" in k or "gemm_wide_kernel" in k or "gemm_tall_kernel" in k or "gemm_tallu_kernel" in k or "gemm_gram_kernel" in k]
 launches = sum(fcalls[k] for k in gemm)
 steps = 3   # bench.py --steps 2 --warmup 1
 # bench.py's roofline block counts the point contractions only (launches_per_step); the M^3 launches of the small-matrix
@@ -68,7 +68,7 @@ json.dump({
     "commit": commit,
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1, config 2, 1 GPU",
     "correction": "FETCH_SIZE (KB) x 1024 x 2 (gfx950 halves wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE (KB) x 1024",
-    "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_gram_kernel + dgp::gemm_f64_kernel (all instantiations)",
+    "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_tallu_kernel + dgp::gemm_gram_kernel + dgp::gemm_f64_kernel (all instantiations)",
     "launches": launches,
     "hbm_bytes_total": total,
     "hbm_bytes_per_launch": (total / steps / point_launches) if point_launches else total / max(launches, 1),
@@ -98,7 +98,7 @@ if mfma_csv:
     busy = mops = gui = ns = 0.0
     big = []
     for d, c in per.items():
-        if "gemm_f64_kernel" not in names[d] and "gemm_wide_kernel" not in names[d] and "gemm_tall_kernel" not in names[d] and "gemm_gram_kernel" not in names[d]:
+        if "gemm_f64_kernel" not in names[d] and "gemm_wide_kernel" not in names[d] and "gemm_tall_kernel" not in names[d] and "gemm_tallu_kernel" not in names[d] and "gemm_gram_kernel" not in names[d]:
             continue
         busy += c["SQ_VALU_MFMA_BUSY_CYCLES"]; mops += c["SQ_INSTS_VALU_MFMA_MOPS_F64"]; gui += c["GRBM_GUI_ACTIVE"]
         ns += dur.get(d, 0)
@@ -109,7 +109,7 @@ if mfma_csv:
                         "clock_ghz": c["GRBM_GUI_ACTIVE"] / XCDS / dur[d]})
     json.dump({
         "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace, bench.py --steps 2 --warmup 1, config 2, 1 GPU",
-        "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_gram_kernel + dgp::gemm_f64_kernel (all instantiations, all launches of the 3 iterations)",
+        "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_tallu_kernel + dgp::gemm_gram_kernel + dgp::gemm_f64_kernel (all instantiations, all launches of the 3 iterations)",
         "formulas": "executed flops = MOPS_F64 x 512; MfmaUtil = MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs) (rocprofv3's own MfmaUtil expression); clock = GRBM_GUI_ACTIVE/8/duration",
         "executed_mfma_flops_per_step": mops * 512 / steps,
         "executed_tflops_over_gemm_time": mops * 512 / ns / 1e3 if ns else None,
@@ -127,12 +127,12 @@ if lds_csv:
     tot = defaultdict(float)
     with open(lds_csv[0], newline="") as f:
         for row in csv.DictReader(f):
-            if "gemm_f64_kernel" in row["Kernel_Name"] or "gemm_wide_kernel" in row["Kernel_Name"] or "gemm_tall_kernel" in row["Kernel_Name"] or "gemm_gram_kernel" in row["Kernel_Name"]:
+            if "gemm_f64_kernel" in row["Kernel_Name"] or "gemm_wide_kernel" in row["Kernel_Name"] or "gemm_tall_kernel" in row["Kernel_Name"] or "gemm_tallu_kernel" in row["Kernel_Name"] or "gemm_gram_kernel" in row["Kernel_Name"]:
                 tot[row["Counter_Name"]] += float(row["Counter_Value"])
     act, conf, gui = tot["SQ_LDS_IDX_ACTIVE"], tot["SQ_LDS_BANK_CONFLICT"], tot["GRBM_GUI_ACTIVE"]
     json.dump({
         "source": "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace, bench.py --steps 2 --warmup 1, config 2, 1 GPU",
-        "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_gram_kernel + dgp::gemm_f64_kernel (all instantiations)",
+        "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_tallu_kernel + dgp::gemm_gram_kernel + dgp::gemm_f64_kernel (all instantiations)",
         "formulas": "bank-conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (cycles the LDS spent re-issuing conflicting lanes over the cycles it was busy); LDS busy = SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE/8 XCDs x 256 CUs) (rocprofv3's LdsUtil expression)",
         "lds_bank_conflict_share": conf / act if act else None,
         "lds_busy_frac": act / (gui / 8 * 256) if gui else None,
