@@ -26,10 +26,6 @@ hipError_t gemm_tall(hipStream_t st, const GemmArgs& a) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
     else cus = 256;
-    // One workgroup fills a CU (LDS and registers): with one per CU nothing else is scheduled while the kernel runs - the
-    // small-matrix chains and the all-reduce on the side streams wait for its end.  Eight CUs stay free for them
-    // (neutral at 10^6 rows, 9.12 -> 9.05 ms per iteration at one eighth of the points, where the chains are 40 percent of it).
-    if (cus >= 64) cus -= 8;
     const char* e = getenv("DGP_TALL_GRID");
     if (e && atoi(e) > 0) cus = atoi(e);
   }
