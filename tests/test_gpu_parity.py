@@ -1273,7 +1273,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/dgp-toolbox_amd")
 from bench import synthetic
 from dgp_dace.gpflow_compat import RBF, Gaussian
 from dgp_dace.models.dgp import DGP
-N, D, M, S = 10112, 8, 256, 10
+N, D, M, S = 10176, 8, 256, 10      # 101760 rows = 795 x 128: the last 256-row tile is half empty
 X, Y, Z = synthetic(N, D, M)
 with contextlib.redirect_stdout(io.StringIO()):
     m = DGP(X, Y, Z, [RBF(1.0, [1.0] * D) for _ in range(3)], [8, 8], Gaussian(), num_samples=S)
@@ -1290,7 +1290,7 @@ def test_tall_tile_kernels_against_the_wide_tile_kernel(tmp_path):
     """The forward product t_d = W_d^T c (gemm_tall.h) and the backward product dC = sum_d [2 vbar_d .* t_d] W_d^T - .. c
     + mbar u^T (gemm_tallu.h) on 256 x 128 tiles add the same k-tiles in the same order as the wide-tile kernel they
     replace (T and dC themselves are bit-identical, tools/wide_bench); only the partial row sums |t_d|^2 are added in
-    another order.  ELBO and gradient of a config-2-shaped model (M = 256, D = 8, 101120 sample points) must therefore
+    another order.  ELBO and gradient of a config-2-shaped model (M = 256, D = 8, 101760 sample points) must therefore
     agree to rounding between DGP_TALL=DGP_TALLU=1 (default) and 0.  The switches are read once per process, hence the
     two child processes (one after the other)."""
     import subprocess, sys, os
