@@ -724,6 +724,9 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 // Host-side dispatcher (defined in gemm_f64.hip)
 enum GemmOp : int { GEMM_NN = 0, GEMM_NT = 1, GEMM_TN = 2 };
 hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args);
+// one-workgroup products of the small models' chains (gemm_small.hip)
+bool gemm_small_ok(GemmOp op, const GemmArgs& a);
+hipError_t gemm_small(hipStream_t st, GemmOp op, const GemmArgs& a);
 // tall-tile kernel for the forward T product (gemm_tall.h / gemm_tall.hip)
 bool gemm_tall_ok(const GemmArgs& a);
 hipError_t gemm_tall(hipStream_t st, const GemmArgs& a);

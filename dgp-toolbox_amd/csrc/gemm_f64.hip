@@ -164,6 +164,7 @@ hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args) {
   GemmArgs a = args;
   if (a.splits < 1) a.splits = 1;
   if (a.batch < 1) a.batch = 1;
+  if (gemm_small_ok(op, a)) return gemm_small(st, op, a);      // M, N, K <= 64: one workgroup, operands staged once
   // row-panel products with a (block-)triangular or dense Mp-wide B: the wide-tile kernel
   if (op == GEMM_NN && !a.no_wide && gemm_tall_ok(a)) return gemm_tall(st, a);      // T = Ct * Wcat at Mp = 256: 256 x 128 tiles
   if (op == GEMM_NN && !a.no_wide && gemm_tallu_ok(a)) return gemm_tallu(st, a);    // dC = [2 vbar .* T] * W^T ... at Mp = 256, likewise

@@ -1,0 +1,98 @@
+// One-workgroup products for the small-matrix chains of small models (Mp <= 64: the Bayesian-optimisation surrogates,
+// SO_BO.py:248-258): C = alpha op(A) op(B) (+ C), M, N, K <= 64, batched.  On the 128 x 64 engine such a product is four
+// k-tiles of one workgroup, each a round trip to L2 behind a barrier: 12-15 us, and a training iteration of config 1 has
+// ~25 of them on its critical path.  Here both operands are staged once (two 33 KB LDS images, k-major), then every
+// thread accumulates a 4 x 4 block of C with VALU FMAs: one load latency + 64 k-steps.
+// Triangular hints are ignored, exactly as the engine does at this size (its skips work on whole 128 x 64 tiles and
+// 64-column k-ranges: op(B)'s zeros are stored, the full C is written).
+#include <cstdlib>
+
+#include "gemm_f64.h"
+
+namespace dgp {
+
+constexpr int SG = 64;          // largest M, N, K
+constexpr int SG_LD = SG + 2;   // row pitch of the LDS images (doubles): 16-byte aligned rows, odd multiple of 16 bytes
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double As[SG][SG_LD];   // As[k][m] = op(A)[m][k]
+  __shared__ __attribute__((aligned(16))) double Bs[SG][SG_LD];   // Bs[k][n] = op(B)[k][n]
+  const int tid = threadIdx.x;
+  const long b = blockIdx.x;
+  const double* __restrict__ A = g.A + b * g.sA;
+  const double* __restrict__ B = g.B + b * g.sB;
+  double* __restrict__ C = g.C + b * g.sC;
+  const int M = (int)g.M, N = (int)g.N, K = (int)g.K;
+  // stage: the fast index of each global read runs along the operand's contiguous dimension
+  for (int x = tid; x < SG * SG; x += 256) {
+    const int r = x >> 6, c = x & 63;
+    if (TA) {          // A stored [k][m]: r = k, c = m
+      As[r][c] = (r < K && c < M) ? A[(long)r * g.lda + c] : 0.0;
+    } else {           // A stored [m][k]: r = m, c = k
+      As[c][r] = (r < M && c < K) ? A[(long)r * g.lda + c] : 0.0;
+    }
+    if (TB) {          // B stored [n][k]: r = n, c = k
+      Bs[c][r] = (r < N && c < K) ? B[(long)r * g.ldb + c] : 0.0;
+    } else {           // B stored [k][n]: r = k, c = n
+      Bs[r][c] = (r < K && c < N) ? B[(long)r * g.ldb + c] : 0.0;
+    }
+  }
+  __syncthreads();
+  const int tx = tid & 15, ty = tid >> 4;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  if (4 * ty < M && 4 * tx < N) {
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+      const d2_t a0 = *reinterpret_cast<const d2_t*>(&As[k][4 * ty]), a1 = *reinterpret_cast<const d2_t*>(&As[k][4 * ty + 2]);
+      const d2_t b0 = *reinterpret_cast<const d2_t*>(&Bs[k][4 * tx]), b1 = *reinterpret_cast<const d2_t*>(&Bs[k][4 * tx + 2]);
+      const double av[4] = {a0[0], a0[1], a1[0], a1[1]}, bv[4] = {b0[0], b0[1], b1[0], b1[1]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = 4 * ty + i;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = 4 * tx + j;
+        if (n >= N) continue;
+        double* c = C + (long)m * g.ldc + n;
+        const double v = g.alpha * acc[i][j];
+        *c = g.beta ? *c + v : v;
+      }
+    }
+  }
+}
+
+bool gemm_small_ok(GemmOp op, const GemmArgs& a) {
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("DGP_SMALL_GEMM"); enabled = e ? atoi(e) : 1; }
+  if (!enabled) return false;
+  if (a.M < 1 || a.N < 1 || a.K < 1 || a.M > SG || a.N > SG || a.K > SG) return false;
+  if (a.splits > 1 || a.batch < 1 || a.batch > 65535) return false;
+  if (a.A == nullptr || a.B == nullptr || a.C == nullptr) return false;
+  if (a.ascale_mode != 0 || a.ascale != nullptr || a.rank != 0 || a.eadd != nullptr || a.emul != nullptr || a.C2 != nullptr || a.c2_only) return false;
+  if (a.epi != 0 || a.a_blocked || a.c_blocked) return false;
+  (void)op;
+  return true;
+}
+
+hipError_t gemm_small(hipStream_t st, GemmOp op, const GemmArgs& a) {
+  const dim3 grid((unsigned)a.batch), block(256);
+  switch (op) {
+    case GEMM_NN: hipLaunchKernelGGL((gemm_small_kernel<false, false>), grid, block, 0, st, a); break;
+    case GEMM_NT: hipLaunchKernelGGL((gemm_small_kernel<false, true>), grid, block, 0, st, a); break;
+    case GEMM_TN: hipLaunchKernelGGL((gemm_small_kernel<true, false>), grid, block, 0, st, a); break;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace dgp
