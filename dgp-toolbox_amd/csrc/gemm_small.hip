@@ -24,19 +24,25 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
   const double* __restrict__ B = g.B + b * g.sB;
   double* __restrict__ C = g.C + b * g.sC;
   const int M = (int)g.M, N = (int)g.N, K = (int)g.K;
-  // stage: the fast index of each global read runs along the operand's contiguous dimension
-  for (int x = tid; x < SG * SG; x += 256) {
-    const int r = x >> 6, c = x & 63;
-    if (TA) {          // A stored [k][m]: r = k, c = m
-      As[r][c] = (r < K && c < M) ? A[(long)r * g.lda + c] : 0.0;
-    } else {           // A stored [m][k]: r = m, c = k
-      As[c][r] = (r < M && c < K) ? A[(long)r * g.lda + c] : 0.0;
-    }
-    if (TB) {          // B stored [n][k]: r = n, c = k
-      Bs[c][r] = (r < N && c < K) ? B[(long)r * g.ldb + c] : 0.0;
-    } else {           // B stored [k][n]: r = k, c = n
-      Bs[r][c] = (r < K && c < N) ? B[(long)r * g.ldb + c] : 0.0;
-    }
+  // stage: the fast index of each global read runs along the operand's contiguous dimension.  All 32 loads of a thread are
+  // requested before the first LDS write (clamped addresses + a select instead of a branch around the load: with the
+  // branch the 16 rounds were 16 dependent trips to L2, 12 us per product)
+  const int c = tid & 63, r0 = tid >> 6;
+  const int ra_n = TA ? K : M, ca_n = TA ? M : K;      // rows / columns of A as stored
+  const int rb_n = TB ? N : K, cb_n = TB ? K : N;      // rows / columns of B as stored
+  double va[16], vb[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int r = r0 + 4 * it;
+    va[it] = A[(long)(r < ra_n ? r : ra_n - 1) * g.lda + (c < ca_n ? c : ca_n - 1)];
+    vb[it] = B[(long)(r < rb_n ? r : rb_n - 1) * g.ldb + (c < cb_n ? c : cb_n - 1)];
+  }
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int r = r0 + 4 * it;
+    const double xa = (r < ra_n && c < ca_n) ? va[it] : 0.0, xb = (r < rb_n && c < cb_n) ? vb[it] : 0.0;
+    if (TA) As[r][c] = xa; else As[c][r] = xa;         // As[k][m]
+    if (TB) Bs[c][r] = xb; else Bs[r][c] = xb;         // Bs[k][n]
   }
   __syncthreads();
   const int tx = tid & 15, ty = tid >> 4;
