@@ -649,6 +649,9 @@ int dgp_comm_init(dgp_ctx* ctx, int32_t rank, int32_t world, const void* id128) 
   void* comm = nullptr;
   RET(nccl_chk(ctx, g_nccl.CommInitRank(&comm, world, id, rank), "ncclCommInitRank"));
   ctx->nccl_comm = comm;
+  // the collectives run beside the backward pass: the persistent kernels leave them a few CUs (gemm_f64.hip)
+  const char* e = getenv("DGP_COMM_RESERVE_CUS");
+  gemm_reserve_cus(e ? atoi(e) : 8);
   return DGP_OK;
 }
 
@@ -658,6 +661,7 @@ int dgp_comm_destroy(dgp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->st);
     (void)g_nccl.CommDestroy(ctx->nccl_comm);
   }
+  if (ctx->nccl_comm) gemm_reserve_cus(0);
   ctx->nccl_comm = nullptr;
   ctx->comm_world = 1;
   ctx->comm_rank = 0;

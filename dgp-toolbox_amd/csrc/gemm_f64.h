@@ -724,6 +724,9 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 // Host-side dispatcher (defined in gemm_f64.hip)
 enum GemmOp : int { GEMM_NN = 0, GEMM_NT = 1, GEMM_TN = 2 };
 hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args);
+// CUs left free by the persistent kernels while a collective may run beside them (gemm_f64.hip)
+void gemm_reserve_cus(int n);
+int gemm_persistent_grid(int cus);
 // one-workgroup products of the small models' chains (gemm_small.hip)
 bool gemm_small_ok(GemmOp op, const GemmArgs& a);
 hipError_t gemm_small(hipStream_t st, GemmOp op, const GemmArgs& a);

@@ -160,6 +160,18 @@ static hipError_t dispatch(hipStream_t st, const GemmArgs& a) {
   return hipSuccess;
 }
 
+// CUs the persistent kernels (one workgroup per CU: tall tiles, Gram) leave free.  A workgroup of theirs fills its CU, so
+// with one on every CU nothing else is scheduled until the kernel ends - which is fine for a single process (DESIGN.md
+// par. 10: the L2 sharing of a full grid is worth more than the free CUs) but makes a collective issued beside the
+// backward pass wait for the end of a kernel.  dgp_comm_init sets it.
+static int g_reserved_cus = 0;
+void gemm_reserve_cus(int n) { g_reserved_cus = n < 0 ? 0 : n; }
+int gemm_persistent_grid(int cus) {
+  if (cus < 64) return cus;
+  const int r = g_reserved_cus < cus / 4 ? g_reserved_cus : cus / 4;
+  return cus - r;
+}
+
 hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args) {
   GemmArgs a = args;
   if (a.splits < 1) a.splits = 1;

@@ -87,7 +87,7 @@ hipError_t gemm_gram(hipStream_t st, const GemmArgs& a) {
   g.ws = a.gram_ws;
   g.P = a.K;
   g.D = a.batch;
-  const unsigned grid = (unsigned)gram_grid();          // (K >= min_k: every workgroup has k-tiles)
+  const unsigned grid = (unsigned)gemm_persistent_grid(gram_grid());          // (K >= min_k: every workgroup has k-tiles; the scratch is sized for the full grid)
   if (g.A) hipLaunchKernelGGL((gemm_gram_kernel<false, 2>), dim3(grid), dim3(512), 0, st, g);
   else if (g.s) hipLaunchKernelGGL((gemm_gram_kernel<true, 1>), dim3(grid), dim3(512), 0, st, g);
   else hipLaunchKernelGGL((gemm_gram_kernel<false, 1>), dim3(grid), dim3(512), 0, st, g);

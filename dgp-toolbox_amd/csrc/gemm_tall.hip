@@ -36,7 +36,8 @@ hipError_t gemm_tall(hipStream_t st, const GemmArgs& a) {
   g.rowsq = a.rowsq; g.rowsq_ld = a.rowsq_ld;
   g.M = a.M; g.D = (int)(a.N / 256);
   const long ntile = ((a.M + 255) / 256) * g.D;
-  const unsigned grid = (unsigned)(ntile < cus ? ntile : cus);
+  const long gmax = gemm_persistent_grid(cus);
+  const unsigned grid = (unsigned)(ntile < gmax ? ntile : gmax);
   if (g.C) hipLaunchKernelGGL(gemm_tall_kernel<true>, dim3(grid), dim3(512), 0, st, g);
   else hipLaunchKernelGGL(gemm_tall_kernel<false>, dim3(grid), dim3(512), 0, st, g);
   return hipGetLastError();

@@ -49,7 +49,8 @@ hipError_t gemm_tallu(hipStream_t st, const GemmArgs& a) {
   g.alpha = a.alpha;
   g.M = a.M; g.D = (int)(a.K / 256);
   const long nb = (a.M + 255) / 256;
-  const unsigned grid = (unsigned)(nb < cus ? nb : cus);
+  const long gmax = gemm_persistent_grid(cus);
+  const unsigned grid = (unsigned)(nb < gmax ? nb : gmax);
   if (a.rank == 8) hipLaunchKernelGGL(gemm_tallu_kernel<8>, dim3(grid), dim3(512), 0, st, g);
   else if (a.rank > 0) hipLaunchKernelGGL(gemm_tallu_kernel<-1>, dim3(grid), dim3(512), 0, st, g);
   else hipLaunchKernelGGL(gemm_tallu_kernel<0>, dim3(grid), dim3(512), 0, st, g);

@@ -67,7 +67,7 @@ hipError_t gemm_wide(hipStream_t st, const GemmArgs& a) {
     if (e && atoi(e) > 0) cus = atoi(e);
   }
   const long tiles = (a.M / WBM) * (a.N / WBN);
-  long gmax = cus;                       // one persistent workgroup per CU (147 KB of LDS each)
+  long gmax = gemm_persistent_grid(cus); // one persistent workgroup per CU (147 KB of LDS each), less those left to a collective
   // With several 256-column tiles per triangular block the tiles of a row panel cost 1 : 2.8 (diagonal block only /
   // diagonal + dense).  A workgroup walks tiles b, b + grid, ...: with grid a multiple of the tiles per panel it would
   // see one kind only.  8 * 31 workgroups make its column tile cycle through all of them.

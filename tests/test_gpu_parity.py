@@ -1279,8 +1279,15 @@ with contextlib.redirect_stdout(io.StringIO()):
     m = DGP(X, Y, Z, [RBF(1.0, [1.0] * D) for _ in range(3)], [8, 8], Gaussian(), num_samples=S)
 ctx = m._sync_model()
 m._sync_data(m.data)
-ctx.grad_partial(S, 5, None)
-e = ctx.grad_finish(want_elbo=True)
+if COMM:
+    # a one-rank RCCL communicator owned by the library: the persistent kernels then leave eight CUs to the collective
+    # (grids of 248 workgroups: other partial-sum boundaries in the Gram kernel, other tile-to-workgroup maps)
+    from dgp_dace._native import Context
+    ctx.comm_init(0, 1, Context.comm_unique_id())
+    e = ctx.grad_step(S, 5, None, want_elbo=True)
+else:
+    ctx.grad_partial(S, 5, None)
+    e = ctx.grad_finish(want_elbo=True)
 g = ctx.grad_get()
 np.savez(OUT, elbo=e, grad=g)
 '''
@@ -1291,19 +1298,21 @@ def test_tall_tile_kernels_against_the_wide_tile_kernel(tmp_path):
     + mbar u^T (gemm_tallu.h) on 256 x 128 tiles add the same k-tiles in the same order as the wide-tile kernel they
     replace (T and dC themselves are bit-identical, tools/wide_bench); only the partial row sums |t_d|^2 are added in
     another order.  ELBO and gradient of a config-2-shaped model (M = 256, D = 8, 101760 sample points) must therefore
-    agree to rounding between DGP_TALL=DGP_TALLU=1 (default) and 0.  The switches are read once per process, hence the
-    two child processes (one after the other)."""
+    agree to rounding between DGP_TALL=DGP_TALLU=1 (default) and 0, and with a communicator attached (persistent grids
+    of 248 instead of 256 workgroups, dgp_grad_step).  The switches are read once per process, hence the child processes
+    (one after the other)."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for flag in ("1", "0"):
-        out = str(tmp_path / f"tall{flag}.npz")
-        code = f"ROOT={root!r}\nOUT={out!r}\n" + TALL_WORKER
+    for flag, comm in (("1", False), ("0", False), ("1", True)):
+        out = str(tmp_path / f"tall{flag}{int(comm)}.npz")
+        code = f"ROOT={root!r}\nOUT={out!r}\nCOMM={comm!r}\n" + TALL_WORKER
         env = dict(os.environ, DGP_TALL=flag, DGP_TALLU=flag)
         p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                            timeout=600)
         assert p.returncode == 0, p.stdout
         res.append(np.load(out))
-    assert abs(float(res[0]["elbo"]) - float(res[1]["elbo"])) < 1e-13 * abs(float(res[1]["elbo"]))
-    np.testing.assert_allclose(res[0]["grad"], res[1]["grad"], rtol=0, atol=1e-12 * np.abs(res[1]["grad"]).max())
+    for k in (0, 2):
+        assert abs(float(res[k]["elbo"]) - float(res[1]["elbo"])) < 1e-13 * abs(float(res[1]["elbo"]))
+        np.testing.assert_allclose(res[k]["grad"], res[1]["grad"], rtol=0, atol=1e-12 * np.abs(res[1]["grad"]).max())
     assert np.isfinite(res[0]["grad"]).all() and np.abs(res[0]["grad"]).max() > 0
