@@ -94,7 +94,8 @@ int main(int argc, char** argv) {
     const long P = timing ? Pt : Pc;
     if (P <= 0) continue;
     for (long Mp : {256L, 512L}) {
-      for (int D : {8, 1}) {
+      const int dalt = getenv("WB_D") ? atoi(getenv("WB_D")) : 1;      // the second block count (1..8)
+      for (int D : {8, dalt}) {
         if (timing && Mp == 512 && D == 1) continue;
         if (timing && Mp == 512 && P > 250000) { /* keep the big arrays bounded */ }
         const long Pm = (timing && Mp == 512) ? std::min(P, 256000L) : P;
