@@ -42,12 +42,13 @@ int dgp_create(int device, void* hip_stream, dgp_ctx** out) {
     for (int i = 0; i < dgp_ctx::kSide && ok; ++i)
       ok = hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) == hipSuccess &&
            hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) ctx->use_side = false;
     for (int i = 0; i < dgp_ctx::kMaxEv && ok; ++i)
       ok = hipEventCreateWithFlags(&ctx->ev_prep[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&ctx->ev_layer[i], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { ctx->ev_prep[0] = nullptr; (void)hipGetLastError(); }
+           hipEventCreateWithFlags(&ctx->ev_red[i], hipEventDisableTiming) == hipSuccess;
+    // one flag for all of them: a partial failure leaves every side path off (dgp_destroy releases what exists)
+    ctx->events_ok = ok;
+    if (!ok) { ctx->use_side = false; (void)hipGetLastError(); }
   }
   *out = ctx;
   return DGP_OK;
@@ -61,6 +62,7 @@ void dgp_destroy(dgp_ctx* ctx) {
   dev_free(ctx->X); dev_free(ctx->Y); dev_free(ctx->scal); dev_free(ctx->info); dev_free(ctx->Xnew);
   if (ctx->ws) (void)hipFree(ctx->ws);
   for (auto e : ctx->prof.ev) (void)hipEventDestroy(e);
+  for (auto e : ctx->prof.marks) (void)hipEventDestroy(e);
   for (int i = 0; i < dgp_ctx::kSide; ++i) {
     if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); }
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
@@ -72,7 +74,7 @@ void dgp_destroy(dgp_ctx* ctx) {
   for (int i = 0; i < dgp_ctx::kMaxEv; ++i) {
     if (ctx->ev_prep[i]) (void)hipEventDestroy(ctx->ev_prep[i]);
     if (ctx->ev_layer[i]) (void)hipEventDestroy(ctx->ev_layer[i]);
-    if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
+    if (ctx->ev_red[i]) (void)hipEventDestroy(ctx->ev_red[i]);
   }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->st);
   delete ctx;
@@ -163,7 +165,7 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
     const long MM = (long)y.Mp * y.Mp;
     const int D = y.d.D_out;
     RET(dev_alloc(ctx, &y.Kuu, MM)); RET(dev_alloc(ctx, &y.Lu, MM)); RET(dev_alloc(ctx, &y.Linv, MM)); RET(dev_alloc(ctx, &y.LinvT, MM));
-    if (y.Mp == 256 && !ctx->gram_ws) RET(dev_alloc(ctx, &ctx->gram_ws, gemm_gram_ws_bytes() / 8));
+    if (y.Mp == 256 && !ctx->gram_ws) RET(dev_alloc(ctx, &ctx->gram_ws, gemm_gram_ws_bytes(ctx->cu_count) / 8));
     RET(dev_alloc(ctx, &y.Lq, MM * D)); RET(dev_alloc(ctx, &y.qmu_p, (long)y.Mp * D));
     RET(dev_alloc(ctx, &y.Wcat, MM * D)); RET(dev_alloc(ctx, &y.u, (long)y.Mp * D)); RET(dev_alloc(ctx, &y.Scat, MM * D)); RET(dev_alloc(ctx, &y.Z1, (long)y.Mp * (y.d.D_in + 1)));
     if (y.d.kernel_kind == DGP_KERNEL_MATERN32 || y.d.kernel_kind == DGP_KERNEL_MATERN52) { RET(dev_alloc(ctx, &y.Euu, MM)); RET(dev_alloc(ctx, &y.kdot, 1)); }
@@ -628,6 +630,8 @@ int nccl_chk(dgp_ctx* ctx, int rc, const char* what) {
 }
 }  // namespace
 
+int dgp_comm_available(void) { return nccl_load(nullptr); }
+
 int dgp_comm_unique_id(void* id128_out) {
   if (!id128_out) return DGP_ERR_INVALID;
   RET(nccl_load(nullptr));
@@ -651,7 +655,7 @@ int dgp_comm_init(dgp_ctx* ctx, int32_t rank, int32_t world, const void* id128) 
   ctx->nccl_comm = comm;
   // the collectives run beside the backward pass: the persistent kernels leave them a few CUs (gemm_f64.hip)
   const char* e = getenv("DGP_COMM_RESERVE_CUS");
-  gemm_reserve_cus(e ? atoi(e) : 8);
+  ctx->reserved_cus = e ? atoi(e) : 8;
   return DGP_OK;
 }
 
@@ -661,7 +665,7 @@ int dgp_comm_destroy(dgp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->st);
     (void)g_nccl.CommDestroy(ctx->nccl_comm);
   }
-  if (ctx->nccl_comm) gemm_reserve_cus(0);
+  ctx->reserved_cus = 0;
   ctx->nccl_comm = nullptr;
   ctx->comm_world = 1;
   ctx->comm_rank = 0;
@@ -678,40 +682,68 @@ int dgp_comm_allreduce(dgp_ctx* ctx, void* device_ptr, int64_t n_doubles) {
 
 // ------------------------------------------------------------------------------- overlapped gradient evaluation
 namespace {
-// backward_chunk hook (last chunk only): layer l's sums are final -> on a side stream: all-reduce its slice, then its chain
+// backward_chunk hook (last chunk only): layer l's sums are final -> all-reduce its slice on the COMM stream (every
+// collective of the communicator is enqueued on that one stream, in the same order on every rank), then the layer's
+// small-matrix chain on one of the two chain streams, while the main stream runs the backward pass of the layers below
 int after_layer_hook(dgp_ctx* ctx, int l) {
   const int nl = (int)ctx->L.size();
   Layer& y = ctx->L[l];
   const long lo = y.acc_Q, hi = (l + 1 < nl) ? ctx->L[l + 1].acc_Q : ctx->n_acc;     // the layer's contiguous slice
   const bool comm = ctx->nccl_comm != nullptr;
-  const bool side = ctx->use_side && nl <= dgp_ctx::kMaxEv && ctx->ev_layer[0] != nullptr;
+  const bool side = ctx->use_side && ctx->events_ok && nl <= dgp_ctx::kMaxEv;
   hipStream_t main_st = ctx->st;
-  hipStream_t st = main_st;
+  hipStream_t chain_st = main_st, comm_st = main_st;
   int w = 0;
   if (side) {
-    w = 1 + ((nl - 1 - l) % 2);                 // alternate the two side streams, top layer first
-    st = ctx->side[w - 1];
+    w = 1 + ((nl - 1 - l) % 2);                 // alternate the two chain streams, top layer first
+    chain_st = ctx->side[w - 1];
+    comm_st = ctx->side[dgp_ctx::kSide - 1];
     HIPCHK(hipEventRecord(ctx->ev_layer[l], main_st));
-    HIPCHK(hipStreamWaitEvent(st, ctx->ev_layer[l], 0));
+    ctx->side_touched[w - 1] = true;
   }
   if (comm) {
+    if (side) { HIPCHK(hipStreamWaitEvent(comm_st, ctx->ev_layer[l], 0)); ctx->side_touched[dgp_ctx::kSide - 1] = true; }
     RET(nccl_chk(ctx, g_nccl.GroupStart(), "ncclGroupStart"));
     int rc = 0;
     if (l == nl - 1)      // the two scalars at the head of the buffer (ELBO data term, likelihood-variance gradient)
-      rc = g_nccl.AllReduce(ctx->acc, ctx->acc, 2, kNcclFloat64, kNcclSum, ctx->nccl_comm, st);
-    if (rc == 0) rc = g_nccl.AllReduce(ctx->acc + lo, ctx->acc + lo, (size_t)(hi - lo), kNcclFloat64, kNcclSum, ctx->nccl_comm, st);
+      rc = g_nccl.AllReduce(ctx->acc, ctx->acc, 2, kNcclFloat64, kNcclSum, ctx->nccl_comm, comm_st);
+    if (rc == 0) rc = g_nccl.AllReduce(ctx->acc + lo, ctx->acc + lo, (size_t)(hi - lo), kNcclFloat64, kNcclSum, ctx->nccl_comm, comm_st);
     const int rc2 = g_nccl.GroupEnd();
     RET(nccl_chk(ctx, rc ? rc : rc2, "ncclAllReduce"));
+    if (side) {
+      HIPCHK(hipEventRecord(ctx->ev_red[l], comm_st));
+      HIPCHK(hipStreamWaitEvent(chain_st, ctx->ev_red[l], 0));
+    }
+  } else if (side) {
+    HIPCHK(hipStreamWaitEvent(chain_st, ctx->ev_layer[l], 0));
   }
-  ctx->st = st;
+  ctx->st = chain_st;
   ctx->sm = ctx->smset[w];
   const int r = finish_layer(ctx, (size_t)l);
   ctx->st = main_st;
   ctx->sm = ctx->smset[0];
-  RET(r);
-  if (side) HIPCHK(hipEventRecord(ctx->ev_done[l], st));
-  return DGP_OK;
+  return r;
 }
+
+// joins every side stream back into the context's stream on EVERY exit of dgp_grad_step (also error returns: chains or
+// all-reduces already enqueued on the side streams must not race with the next call's memset of the partial-sum buffer)
+struct SideJoin {
+  dgp_ctx* ctx;
+  hipStream_t main;
+  bool on;
+  ~SideJoin() {
+    if (!on) return;
+    ctx->st = main;
+    ctx->sm = ctx->smset[0];
+    for (int i = 0; i < dgp_ctx::kSide; ++i) {
+      if (!ctx->side_touched[i]) continue;
+      (void)hipEventRecord(ctx->ev_join[i], ctx->side[i]);
+      (void)hipStreamWaitEvent(main, ctx->ev_join[i], 0);
+      ctx->side_touched[i] = false;
+    }
+    for (int l = 0; l < dgp_ctx::kMaxEv; ++l) ctx->prep_wait[l] = false;   // (all prep chains are joined now)
+  }
+};
 }  // namespace
 
 int dgp_grad_step(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs, double* elbo_out) {
@@ -720,33 +752,34 @@ int dgp_grad_step(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* z
   HIPCHK(hipSetDevice(ctx->device));
   ctx->grad_ready = false;
   if (zs) RET(upload_zs(ctx, zs, S, ctx->N));
-  RET(prep(ctx, true, true));
-  HIPCHK(hipMemsetAsync(ctx->acc, 0, ctx->n_acc * 8, ctx->st));
-  long Nc = 0;
-  const long lo = ctx->batch_n ? ctx->batch_lo : 0, hi = ctx->batch_n ? ctx->batch_lo + ctx->batch_n : ctx->N;
-  RET(ensure_ws(ctx, hi - lo, S, true, &Nc));
-  Layer& last = ctx->L.back();
-  const bool dedup_last = ctx->L.size() == 1;
   const int nl = (int)ctx->L.size();
-  bool hooked = false;
-  for (long n0 = lo; n0 < hi; n0 += Nc) {
-    const long nc = std::min(Nc, hi - n0);
-    RET(forward_chunk(ctx, ctx->X, ctx->N, n0, nc, S, seed, zs != nullptr, ctx->n_goff));
-    {
-      ProfScope ps(ctx, 1, 0, 0);
-      HIPCHK(gauss_lik(ctx->st, last.mean, last.var, ctx->Y, n0, nc, S, dedup_last ? 1 : 0, ctx->Dy,
-                       P(ctx, ctx->n_params - 1), ctx->acc + 0, ctx->acc + 1, last.mbar, last.vbar,
-                       ctx->acc + last.acc_dvar, ctx->data_scale));
+  {
+    SideJoin join{ctx, ctx->st, ctx->use_side && ctx->events_ok};
+    RET(prep(ctx, true, true));
+    HIPCHK(hipMemsetAsync(ctx->acc, 0, ctx->n_acc * 8, ctx->st));
+    long Nc = 0;
+    const long lo = ctx->batch_n ? ctx->batch_lo : 0, hi = ctx->batch_n ? ctx->batch_lo + ctx->batch_n : ctx->N;
+    RET(ensure_ws(ctx, hi - lo, S, true, &Nc));
+    Layer& last = ctx->L.back();
+    const bool dedup_last = ctx->L.size() == 1;
+    bool hooked = false;
+    for (long n0 = lo; n0 < hi; n0 += Nc) {
+      const long nc = std::min(Nc, hi - n0);
+      RET(forward_chunk(ctx, ctx->X, ctx->N, n0, nc, S, seed, zs != nullptr, ctx->n_goff));
+      {
+        ProfScope ps(ctx, 1, 0, 0);
+        HIPCHK(gauss_lik(ctx->st, last.mean, last.var, ctx->Y, n0, nc, S, dedup_last ? 1 : 0, ctx->Dy,
+                         P(ctx, ctx->n_params - 1), ctx->acc + 0, ctx->acc + 1, last.mbar, last.vbar,
+                         ctx->acc + last.acc_dvar, ctx->data_scale));
+      }
+      BwdOpts o{ctx->X, ctx->N, ctx->n_goff, true, false};
+      if (n0 + nc >= hi) { o.after_layer = after_layer_hook; hooked = true; }     // sums are final in the last chunk only
+      RET(backward_chunk(ctx, n0, nc, S, seed, zs != nullptr, o));
     }
-    BwdOpts o{ctx->X, ctx->N, ctx->n_goff, true, false};
-    if (n0 + nc >= hi) { o.after_layer = after_layer_hook; hooked = true; }     // sums are final in the last chunk only
-    RET(backward_chunk(ctx, n0, nc, S, seed, zs != nullptr, o));
-  }
-  if (!hooked) {          // no data points on this rank: the chains still have to run (KL part), after the all-reduces
-    for (int l = nl - 1; l >= 0; --l) RET(after_layer_hook(ctx, l));
-  }
-  if (ctx->use_side && nl <= dgp_ctx::kMaxEv && ctx->ev_layer[0] != nullptr)
-    for (int l = 0; l < nl; ++l) HIPCHK(hipStreamWaitEvent(ctx->st, ctx->ev_done[l], 0));
+    if (!hooked) {          // no data points on this rank: the chains still have to run (KL part), after the all-reduces
+      for (int l = nl - 1; l >= 0; --l) RET(after_layer_hook(ctx, l));
+    }
+  }   // side streams joined
   RET(finish_tail(ctx));
   if (elbo_out) return dgp_last_elbo(ctx, elbo_out);
   return DGP_OK;
@@ -982,6 +1015,34 @@ int dgp_prof_read(dgp_ctx* ctx, int32_t n_cat, double* ms_out, int64_t* launches
   return DGP_OK;
 }
 
+int dgp_prof_mark(dgp_ctx* ctx) {
+  if (!ctx) return DGP_ERR_INVALID;
+  Prof& p = ctx->prof;
+  if (p.marks_used == p.marks.size()) {
+    if (p.marks.size() >= 65536) return fail(ctx, DGP_ERR_INVALID, "dgp_prof_mark: too many marks (read them first)");
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    p.marks.push_back(e);
+  }
+  HIPCHK(hipEventRecord(p.marks[p.marks_used++], ctx->st));
+  return DGP_OK;
+}
+
+int dgp_prof_marks_read(dgp_ctx* ctx, int32_t n_max, double* ms_between_out, int32_t* n_out) {
+  if (!ctx || n_max < 0 || (n_max > 0 && !ms_between_out)) return fail(ctx, DGP_ERR_INVALID, "dgp_prof_marks_read: bad arguments");
+  Prof& p = ctx->prof;
+  int n = 0;
+  if (p.marks_used > 0) HIPCHK(hipEventSynchronize(p.marks[p.marks_used - 1]));
+  for (size_t i = 0; i + 1 < p.marks_used && n < n_max; ++i, ++n) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, p.marks[i], p.marks[i + 1]));
+    ms_between_out[n] = ms;
+  }
+  p.marks_used = 0;
+  if (n_out) *n_out = n;
+  return DGP_OK;
+}
+
 // ----------------------------------------------------------------------------------- unit-level hooks
 int dgp_dev_gemm(dgp_ctx* ctx, int32_t op, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B,
                  int64_t ldb, double* C, int64_t ldc, double alpha, int32_t beta, int32_t splits, int32_t tri,
@@ -996,11 +1057,14 @@ int dgp_dev_gemm(dgp_ctx* ctx, int32_t op, int64_t M, int64_t N, int64_t K, cons
   RET(dev_alloc(ctx, &dC, (size_t)M * ldc));
   // reductions over the points with a 256 x 256 lower-triangular output: the Gram kernel's scratch (gemm_gram.h)
   if (op == GEMM_TN && M == 256 && N == 256 && tri == TRI_OUT_LOWER && !ctx->gram_ws)
-    RET(dev_alloc(ctx, &ctx->gram_ws, gemm_gram_ws_bytes() / 8));
+    RET(dev_alloc(ctx, &ctx->gram_ws, gemm_gram_ws_bytes(ctx->cu_count) / 8));
   HIPCHK(hipMemcpy(dA, A, (size_t)ar * lda * 8, hipMemcpyHostToDevice));
   if (!same) HIPCHK(hipMemcpy(dB, B, (size_t)br * ldb * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dC, C, (size_t)M * ldc * 8, hipMemcpyHostToDevice));
-  int rc = G(ctx, 0, (GemmOp)op, M, N, K, dA, lda, dB, ldb, dC, ldc, alpha, beta, 1, 0, 0, 0, splits, tri, triblk);
+  GemmArgs ga = mk(M, N, K, dA, lda, dB, ldb, dC, ldc, alpha, beta);
+  ga.splits = splits; ga.tri = tri; ga.triblk = triblk;
+  if (ctx->gram_ws) { ga.gram_ws = ctx->gram_ws; ga.gram_ws_bytes = gemm_gram_ws_bytes(ctx->cu_count); }
+  int rc = GX(ctx, 0, (GemmOp)op, ga);
   if (rc == DGP_OK) {
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipMemcpy(C, dC, (size_t)M * ldc * 8, hipMemcpyDeviceToHost));
@@ -1009,7 +1073,7 @@ int dgp_dev_gemm(dgp_ctx* ctx, int32_t op, int64_t M, int64_t N, int64_t K, cons
       HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
       HIPCHK(hipEventRecord(e0, ctx->st));
       for (int r = 0; r < repeats && rc == DGP_OK; ++r)
-        rc = G(ctx, 0, (GemmOp)op, M, N, K, dA, lda, dB, ldb, dC, ldc, alpha, beta, 1, 0, 0, 0, splits, tri, triblk);
+        rc = GX(ctx, 0, (GemmOp)op, ga);
       HIPCHK(hipEventRecord(e1, ctx->st));
       HIPCHK(hipEventSynchronize(e1));
       float ms = 0.f;
@@ -1032,7 +1096,7 @@ int dgp_dev_gram(dgp_ctx* ctx, const double* C, const double* s, int64_t Pn, int
   RET(dev_alloc(ctx, &dC, (size_t)Pn * Mp));
   RET(dev_alloc(ctx, &dG, (size_t)D * MM));
   if (s) RET(dev_alloc(ctx, &ds, (size_t)Pn * D));
-  if (!ctx->gram_ws) RET(dev_alloc(ctx, &ctx->gram_ws, gemm_gram_ws_bytes() / 8));
+  if (!ctx->gram_ws) RET(dev_alloc(ctx, &ctx->gram_ws, gemm_gram_ws_bytes(ctx->cu_count) / 8));
   HIPCHK(hipMemcpy(dC, C, (size_t)Pn * Mp * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dG, G, (size_t)D * MM * 8, hipMemcpyHostToDevice));
   if (s) HIPCHK(hipMemcpy(ds, s, (size_t)Pn * D * 8, hipMemcpyHostToDevice));
@@ -1040,6 +1104,7 @@ int dgp_dev_gram(dgp_ctx* ctx, const double* C, const double* s, int64_t Pn, int
   GemmArgs a = mk(Mp, Mp, Pn, dC, Mp, dC, Mp, dG, Mp, 1.0, 1);
   a.batch = D; a.sC = MM; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp) * D, Pn, (long)Mp * 8);
   if (s) { a.ascale = ds; a.as_ld = D; a.ascale_mode = 2; }
+  a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = gemm_gram_ws_bytes(ctx->cu_count);
   int rc = GX(ctx, 0, GEMM_TN, a);
   if (rc == DGP_OK) {
     HIPCHK(hipStreamSynchronize(ctx->st));
@@ -1047,6 +1112,96 @@ int dgp_dev_gram(dgp_ctx* ctx, const double* C, const double* s, int64_t Pn, int
   }
   dev_free(dC); dev_free(dG); dev_free(ds);
   return rc;
+}
+
+int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, const double* Kt, const double* Linv,
+                           const double* Wcat, const double* u, const double* vbar, const double* mbar, double* Ct,
+                           double* cn, double* T, double* tn, double* mean0, double* Cbar, double* g, double* du,
+                           int32_t* engines) {
+  if (!ctx || Pn <= 0 || Mp <= 0 || Mp % 64 != 0 || D < 1 || D > 64 || !Kt || !Linv || !Wcat || !u || !vbar || !mbar || !Ct || !cn ||
+      !T || !tn || !mean0 || !Cbar || !g || !du)
+    return fail(ctx, DGP_ERR_INVALID, "dgp_dev_layer_products: bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  const long P = Pn, Pm = pad_rows(P), MM = (long)Mp * Mp, DM = (long)D * Mp;
+  const int maxpl = Mp / 32;
+  std::vector<double*> bufs;
+  auto take = [&](double** p, size_t n, bool zero) -> int {
+    RET(dev_alloc(ctx, p, n));
+    bufs.push_back(*p);
+    if (zero) HIPCHK(hipMemsetAsync(*p, 0, n * 8, ctx->st));
+    return DGP_OK;
+  };
+  struct Free { std::vector<double*>& b; ~Free() { for (double* q : b) (void)hipFree(q); } } freer{bufs};
+  double *dKt, *dLinv, *dLinvT, *dW, *dS, *du_, *dvb, *dmb, *dCt, *cnp, *tnp, *dT, *dm0, *dCb, *dKb, *dG, *ddu;
+  RET(take(&dKt, (size_t)Pm * Mp, true)); RET(take(&dLinv, MM, false)); RET(take(&dLinvT, MM, false));
+  RET(take(&dW, (size_t)Mp * DM, false)); RET(take(&dS, (size_t)Mp * DM, false)); RET(take(&du_, (size_t)Mp * D, false));
+  RET(take(&dvb, (size_t)Pm * D, true)); RET(take(&dmb, (size_t)Pm * D, true));
+  RET(take(&dCt, (size_t)Pm * Mp, true)); RET(take(&cnp, (size_t)Pm * maxpl, true)); RET(take(&tnp, (size_t)Pm * maxpl * D, true));
+  RET(take(&dT, (size_t)Pm * DM, true)); RET(take(&dm0, (size_t)Pm * D, true)); RET(take(&dCb, (size_t)Pm * Mp, true));
+  RET(take(&dKb, (size_t)Pm * Mp, true)); RET(take(&dG, (size_t)Pm * Mp, true)); RET(take(&ddu, (size_t)Mp * D, true));
+  HIPCHK(hipMemcpyAsync(dKt, Kt, (size_t)P * Mp * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(dLinv, Linv, MM * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(dW, Wcat, (size_t)Mp * DM * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(du_, u, (size_t)Mp * D * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(dvb, vbar, (size_t)P * D * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(dmb, mbar, (size_t)P * D * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(wcat_transpose(ctx->st, dLinv, Mp, 1, dLinvT));         // as prep() does
+  HIPCHK(wcat_transpose(ctx->st, dW, Mp, D, dS));                // Scat = W_d^T stacked (stored-T form)
+  // forward (forward_chunk)
+  GemmArgs aC = args_Ct(Pm, Mp, dKt, dLinvT, dCt, cnp);
+  GemmArgs aT = args_T(Pm, Mp, D, dCt, dW, dT, tnp, ctx->blocked_t);
+  const bool wide = gemm_wide_ok(aC) && gemm_wide_ok(aT);
+  int nplane = 0;
+  RET(launch_Ct_T(ctx, aC, aT, dLinv, P, &nplane));
+  RET(GX(ctx, 0, GEMM_NN, args_mean0(Pm, Mp, D, dCt, du_, dm0)));
+  // backward (backward_chunk, stored-T form)
+  GemmArgs aB = args_Cbar(Pm, Mp, D, dT, dS, dCb, dvb, dCt, dmb, du_, ctx->blocked_t);
+  RET(GX(ctx, 0, GEMM_NN, aB));
+  GemmArgs aG = args_g(Pm, Mp, dCb, dLinv, dKb, dKt, dG);
+  RET(GX(ctx, 0, GEMM_NN, aG));
+  GemmArgs aU = args_du(ctx, P, Mp, D, dCt, dmb, ddu);
+  RET(GX(ctx, 0, GEMM_TN, aU));
+  if (engines) {
+    GemmArgs c2 = aC, t2 = aT;
+    if (!wide) { c2.B = dLinv; c2.no_wide = 1; t2.no_wide = 1; }
+    engines[0] = gemm_engine_of(wide ? GEMM_NN : GEMM_NT, c2);
+    engines[1] = gemm_engine_of(GEMM_NN, t2);
+    engines[2] = gemm_engine_of(GEMM_NN, aB);
+    engines[3] = gemm_engine_of(GEMM_NN, aG);
+    engines[4] = gemm_engine_of(GEMM_TN, aU);
+  }
+  // results: row-norm planes summed as finalize_layer sums them, T taken out of the engine's blocked layout
+  std::vector<double> hpl((size_t)Pm * maxpl * D), hT((size_t)Pm * DM);
+  HIPCHK(hipMemcpyAsync(Ct, dCt, (size_t)P * Mp * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipMemcpyAsync(mean0, dm0, (size_t)P * D * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipMemcpyAsync(Cbar, dCb, (size_t)P * Mp * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipMemcpyAsync(g, dG, (size_t)P * Mp * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipMemcpyAsync(du, ddu, (size_t)Mp * D * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipMemcpyAsync(hT.data(), dT, (size_t)Pm * DM * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipMemcpyAsync(hpl.data(), cnp, (size_t)Pm * nplane * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  for (long p = 0; p < P; ++p) {
+    double s = 0.0;
+    for (int q = 0; q < nplane; ++q) s += hpl[(size_t)q * Pm + p];
+    cn[p] = s;
+  }
+  HIPCHK(hipMemcpy(hpl.data(), tnp, (size_t)Pm * nplane * D * 8, hipMemcpyDeviceToHost));
+  for (long p = 0; p < P; ++p)
+    for (int d = 0; d < D; ++d) {
+      double s = 0.0;
+      for (int q = 0; q < nplane; ++q) s += hpl[((size_t)d * nplane + q) * Pm + p];
+      tn[p * D + d] = s;
+    }
+  if (aT.c_blocked) {      // gemm_f64.h: panels of 128 rows, inside a panel blocks of 16 columns, each block 128 x 16 row-major
+    for (long p = 0; p < P; ++p) {
+      const double* panel = hT.data() + (p / 128) * 128 * DM;
+      const long r = p % 128;
+      for (long n = 0; n < DM; ++n) T[p * DM + n] = panel[(n / 16) * (128 * 16) + r * 16 + (n % 16)];
+    }
+  } else {
+    memcpy(T, hT.data(), (size_t)P * DM * 8);
+  }
+  return DGP_OK;
 }
 
 int dgp_dev_chol(dgp_ctx* ctx, double* A, int32_t M, int32_t batch) {

@@ -61,6 +61,8 @@ struct Prof {
   size_t used = 0;
   double ms[kNCat] = {0, 0, 0, 0}, flops[kNCat] = {0, 0, 0, 0}, bytes[kNCat] = {0, 0, 0, 0};
   long launches[kNCat] = {0, 0, 0, 0};
+  std::vector<hipEvent_t> marks;      // step boundaries recorded by dgp_prof_mark (timing events on the context's stream)
+  size_t marks_used = 0;
 };
 
 }  // namespace
@@ -68,6 +70,7 @@ struct Prof {
 struct dgp_ctx {
   int device = 0;
   int cu_count = 0;
+  int reserved_cus = 0;     // CUs the persistent kernels of THIS context leave to its collective (dgp_comm_init)
   hipStream_t st = nullptr;
   bool own_stream = false;
   std::string err;
@@ -124,8 +127,10 @@ struct dgp_ctx {
   Prof prof;
   // overlap machinery of dgp_grad_step: per-layer events (prep done / backward left the layer / finish chain done)
   static constexpr int kMaxEv = 16;
-  hipEvent_t ev_prep[kMaxEv] = {nullptr}, ev_layer[kMaxEv] = {nullptr}, ev_done[kMaxEv] = {nullptr};
+  hipEvent_t ev_prep[kMaxEv] = {nullptr}, ev_layer[kMaxEv] = {nullptr}, ev_red[kMaxEv] = {nullptr};
+  bool events_ok = false;   // every stream and event above exists (tested wherever the side path is taken)
   bool prep_wait[kMaxEv] = {false};
+  bool side_touched[kSide] = {false};   // side streams that got work in the current dgp_grad_step (joined at its end)
   // library-owned RCCL communicator (dgp_comm_init); the functions come from dlopen("librccl.so.1")
   // captured-graph training loop (dgp_adam_iterations): device-side iteration state, ELBO log, the instantiated graph
   long ws_key_N = -1, ws_key_Nc = 0, ws_key_limit = 0;   // last workspace request (ensure_ws)
@@ -230,15 +235,17 @@ int G(dgp_ctx* ctx, int cat, GemmOp op, long M, long N, long K, const double* A,
   a.alpha = alpha; a.beta = beta; a.tri = tri; a.triblk = triblk;
   if (M <= 0 || N <= 0 || K <= 0) return DGP_OK;
   ProfScope ps(ctx, cat, flops, bytes);
-  if (!a.gram_ws && ctx->gram_ws) { a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = gemm_gram_ws_bytes(); }   // (gemm_gram.h; only
-  HIPCHK(gemm_f64(ctx->st, op, a));                       //  reductions over >= 8192 points are eligible: never a chain product)
+  a.cu_count = ctx->cu_count; a.reserve_cus = ctx->reserved_cus;
+  HIPCHK(gemm_f64(ctx->st, op, a));
   return DGP_OK;
 }
 
 int GX(dgp_ctx* ctx, int cat, GemmOp op, GemmArgs a, double flops = 0.0, double bytes = 0.0) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return DGP_OK;
   ProfScope ps(ctx, cat, flops, bytes);
-  if (!a.gram_ws && ctx->gram_ws) { a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = gemm_gram_ws_bytes(); }
+  // (the Gram kernel's scratch - one buffer per context, not stream-safe - is attached only by the callers that reduce
+  //  over the points on the context's main stream: backward_chunk's G_d / Q' and the unit hooks)
+  a.cu_count = ctx->cu_count; a.reserve_cus = ctx->reserved_cus;
   HIPCHK(gemm_f64(ctx->st, op, a));
   return DGP_OK;
 }
@@ -511,11 +518,11 @@ int prep(dgp_ctx* ctx, bool train = false, bool overlap = false) {
   ctx->prep_level = 0;        // set only once every layer's chain has been enqueued: an error return below must not
                               // leave a half-built factorisation marked as current
   HIPCHK(hipMemsetAsync(ctx->scal, 0, 4 * sizeof(double), ctx->st));
-  const bool ov = overlap && ctx->use_side && ctx->L.size() > 1 && ctx->L.size() <= (size_t)dgp_ctx::kMaxEv && ctx->ev_prep[0] != nullptr;
+  const bool ov = overlap && ctx->use_side && ctx->events_ok && ctx->L.size() > 1 && ctx->L.size() <= (size_t)dgp_ctx::kMaxEv;
   hipStream_t main_st = ctx->st;
   if (ov) {
     HIPCHK(hipEventRecord(ctx->ev_fork, main_st));
-    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0));
+    for (int i = 0; i < 2; ++i) { HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0)); ctx->side_touched[i] = true; }
   }
   {
   LayerFork fork(ctx, ov ? 1 : (int)ctx->L.size());
@@ -580,6 +587,71 @@ ZSource zsrc_of(dgp_ctx* ctx, int l, bool use_zs, uint64_t seed, long n_goff, lo
   return z;
 }
 
+// ------------------------------------------------------------------------------- the layer's point contractions
+// Their GemmArgs are built in ONE place: forward_chunk / backward_chunk and the unit hook dgp_dev_layer_products (which the
+// tests compare element by element with NumPy at sizes where the wide-tile and tall-tile kernels are selected) issue
+// literally the same launches.
+// c = Lu^-1 k: Ct = Kt * Linv^T as an NN product with the upper-triangular LinvT, row sums |c|^2 into planes
+GemmArgs args_Ct(long Pm, int Mp, const double* Kt, const double* LinvT, double* Ct, double* cnp) {
+  GemmArgs a = mk(Pm, Mp, Mp, Kt, Mp, LinvT, Mp, Ct, Mp);
+  a.tri = TRI_B_UPPER; a.triblk = Mp; a.epi = 2; a.rowsq = cnp; a.rowsq_ld = Pm;
+  return a;
+}
+// t_d = W_d^T c: T = Ct * Wcat (W_d lower), row sums |t_d|^2 into planes; T itself (blocked layout) only when Tt != nullptr
+GemmArgs args_T(long Pm, int Mp, int D, const double* Ct, const double* Wcat, double* Tt, double* tnp, bool blocked) {
+  GemmArgs a = mk(Pm, (long)D * Mp, Mp, Ct, Mp, Wcat, (long)D * Mp, Tt, (long)D * Mp);
+  a.tri = TRI_B_LOWER; a.triblk = Mp; a.epi = Tt ? 2 : 1; a.rowsq = tnp; a.rowsq_ld = Pm;
+  a.c_blocked = (Tt && blocked) ? 1 : 0;       // t_d is read back only by the dC product: blocked layout
+  return a;
+}
+// dC = sum_d 2 vbar_d (W_d t_d - c) + mbar u^T: [2 vbar .* T] * WTcat, W_d lower => k <= n per block; "- c" and the rank-D
+// term in the epilogue
+GemmArgs args_Cbar(long Pm, int Mp, int D, const double* Tt, const double* Scat, double* Cbar, const double* vbar,
+                   const double* Ct, const double* mbar, const double* u, bool blocked) {
+  const long DM = (long)D * Mp;
+  GemmArgs a = mk(Pm, Mp, DM, Tt, DM, Scat, Mp, Cbar, Mp, 2.0, 0);
+  a.ascale = vbar; a.as_ld = D; a.a_kblk = Mp; a.ascale_mode = 1; a.a_wrap = 0;
+  a.a_blocked = blocked ? 1 : 0;
+  a.tri = TRI_B_UPPER; a.triblk = Mp;
+  a.eadd = Ct; a.eadd_nsc = D;
+  a.rowf = mbar; a.colf = u; a.rank = D;
+  return a;
+}
+// dK = dC * Linv (Linv lower) and, with `emul`, only its second output g = dK .* emul
+GemmArgs args_g(long Pm, int Mp, const double* Cbar, const double* Linv, double* Kbar, const double* emul, double* Gt) {
+  GemmArgs a = mk(Pm, Mp, Mp, Cbar, Mp, Linv, Mp, Kbar, Mp);
+  a.tri = TRI_B_LOWER; a.triblk = Mp;
+  if (emul) { a.emul = emul; a.C2 = Gt; a.c2_only = 1; }
+  return a;
+}
+
+// mean (before the mean function) = Ct u, and its adjoint reduction over the points du += Ct^T mbar
+GemmArgs args_mean0(long Pm, int Mp, int D, const double* Ct, const double* u, double* mean0) {
+  return mk(Pm, D, Mp, Ct, Mp, u, D, mean0, D);
+}
+GemmArgs args_du(dgp_ctx* ctx, long Pl, int Mp, int D, const double* Ct, const double* mbar, double* du) {
+  GemmArgs a = mk(Mp, D, Pl, Ct, Mp, mbar, D, du, D, 1.0, 1);
+  a.splits = pick_splits(ctx, Mp, D, Pl);
+  return a;
+}
+
+// Ct then T: on the wide-tile / tall-tile kernels when BOTH apply (they share the layout of the row-norm planes: Mp/128
+// planes), else both on the 128 x 64 engine (Mp/32 planes, the triangular solve as an NT product with the lower Linv)
+int launch_Ct_T(dgp_ctx* ctx, GemmArgs aC, GemmArgs aT, const double* Linv, long Pl, int* nplane) {
+  const long Mp = aC.N, D = aT.N / Mp;
+  const double tri1 = (double)Pl * Mp * (Mp + 1.0);
+  const bool wide = gemm_wide_ok(aC) && gemm_wide_ok(aT);
+  *nplane = wide ? (int)(Mp / 128) : (int)(Mp / 32);
+  if (wide) {
+    RET(GX(ctx, 0, GEMM_NN, aC, tri1, (double)Pl * Mp * 16));
+  } else {
+    aC.B = Linv; aC.no_wide = 1; aT.no_wide = 1;
+    RET(GX(ctx, 0, GEMM_NT, aC, tri1, (double)Pl * Mp * 16));
+  }
+  RET(GX(ctx, 0, GEMM_NN, aT, tri1 * D, (double)Pl * Mp * 8 * (aT.C ? 1 + D : 1)));
+  return DGP_OK;
+}
+
 // ------------------------------------------------------------------------------- forward over one chunk
 int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc, int S, uint64_t seed, bool use_zs,
                   long n_goff) {
@@ -595,17 +667,11 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
       HIPCHK(hipStreamWaitEvent(ctx->st, ctx->ev_prep[l], 0));
       ctx->prep_wait[l] = false;
     }
-    const double tri1 = (double)Pl * Mp * (Mp + 1.0);   // 2 * M(M+1)/2 flops per point
     // c = Lu^-1 k (|c|^2 partials) and t_d = W_d^T c (|t_d|^2 partials always leave the kernel; t_d itself only for
     // the backward pass, store_t).  Both run on the wide-tile kernel (gemm_wide.h: 2 partial planes per 256 columns)
     // when it applies, else on the 128 x 64 engine (Mp/32 planes, the triangular solve as an NT product).
-    GemmArgs aC = mk(Pm, Mp, Mp, y.Kt, Mp, y.LinvT, Mp, y.Ct, Mp);
-    aC.tri = TRI_B_UPPER; aC.triblk = Mp; aC.epi = 2; aC.rowsq = y.cnp; aC.rowsq_ld = Pm;
-    GemmArgs aT = mk(Pm, (long)D * Mp, Mp, y.Ct, Mp, y.Wcat, (long)D * Mp, y.Tt, (long)D * Mp);
-    aT.tri = TRI_B_LOWER; aT.triblk = Mp; aT.epi = y.Tt ? 2 : 1; aT.rowsq = y.tnp; aT.rowsq_ld = Pm;
-    aT.c_blocked = (y.Tt && ctx->blocked_t) ? 1 : 0;       // t_d is read back only by the dC product below: blocked layout
-    const bool wide = gemm_wide_ok(aC) && gemm_wide_ok(aT);
-    const int nplane = wide ? Mp / 128 : Mp / 32;
+    GemmArgs aC = args_Ct(Pm, Mp, y.Kt, y.LinvT, y.Ct, y.cnp);
+    GemmArgs aT = args_T(Pm, Mp, D, y.Ct, y.Wcat, y.Tt, y.tnp, ctx->blocked_t);
     {
       ProfScope ps(ctx, 1, 0, (double)Pl * (Mp + Din) * 8);
       if (y.d.kernel_kind == DGP_KERNEL_MF)
@@ -614,14 +680,9 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
         HIPCHK(rbf_kuf(ctx->st, y.d.kernel_kind, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
                        y.Kt, y.Et));
     }
-    if (wide) {
-      RET(GX(ctx, 0, GEMM_NN, aC, tri1, (double)Pl * Mp * 16));
-    } else {
-      aC.B = y.Linv; aC.no_wide = 1; aT.no_wide = 1;
-      RET(GX(ctx, 0, GEMM_NT, aC, tri1, (double)Pl * Mp * 16));
-    }
-    RET(GX(ctx, 0, GEMM_NN, aT, tri1 * D, (double)Pl * Mp * 8 * (y.Tt ? 1 + D : 1)));
-    RET(GX(ctx, 0, GEMM_NN, mk(Pm, D, Mp, y.Ct, Mp, y.u, D, y.mean0, D), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
+    int nplane = 0;
+    RET(launch_Ct_T(ctx, aC, aT, y.Linv, Pl, &nplane));
+    RET(GX(ctx, 0, GEMM_NN, args_mean0(Pm, Mp, D, y.Ct, y.u, y.mean0), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
     {
       ProfScope ps(ctx, 1, 0, (double)Pl * nplane * 8 * (1 + D));
       HIPCHK(finalize_layer(ctx->st, y.cnp, y.tnp, nplane, Pm, y.mean0, Xin, row0, Pl, Nc, S, dedup ? 1 : 0, Din, D,
@@ -659,12 +720,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     const long DM = (long)D * Mp, MM = (long)Mp * Mp;
     const double tri1 = (double)Pl * Mp * (Mp + 1.0);
     if (y.Tt) {  // dC = sum_d 2 vbar_d (W_d t_d - c): [2 vbar .* T] * WTcat, W_d lower => k <= n per block; "- c" in the epilogue
-      GemmArgs a = mk(Pm, Mp, DM, y.Tt, DM, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);
-      a.ascale = y.vbar; a.as_ld = D; a.a_kblk = Mp; a.ascale_mode = 1; a.a_wrap = 0;
-      a.a_blocked = ctx->blocked_t ? 1 : 0;
-      a.tri = TRI_B_UPPER; a.triblk = Mp;
-      a.eadd = y.Ct; a.eadd_nsc = D;
-      a.rowf = y.mbar; a.colf = y.u; a.rank = D;             // + mbar u^T in the epilogue
+      GemmArgs a = args_Cbar(Pm, Mp, D, y.Tt, y.Scat, ctx->Cbar, y.vbar, y.Ct, y.mbar, y.u, ctx->blocked_t);
       RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 8 * (2 + D)));
     } else {  // dC = sum_d 2 vbar_d .* (C S'_d)      (A operand scaled on the fly; K = D*Mp re-reads C per block)
       GemmArgs a = mk(Pm, Mp, DM, y.Ct, Mp, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);
@@ -674,14 +730,10 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 16));
     }
     {
-      GemmArgs a = mk(Pm, Mp, Mp, ctx->Cbar, Mp, y.Linv, Mp, ctx->Kbar, Mp);
-      a.tri = TRI_B_LOWER; a.triblk = Mp;
-      if (y.d.kernel_kind != DGP_KERNEL_MF) {
-        a.emul = y.Et ? y.Et : y.Kt; a.C2 = ctx->Gt;        // g = dK .* e (e = -2 dk/dr2; = k for the squared exponential)
-        // dK itself has one more reader, Q = dK^T C = Linv^T (Cbar^T C): that reduction takes Cbar instead (finish_layer
-        // applies Linv^T to the summed 256 x 256 result), so the stationary kernels never write dK: 2 GB per 10^6 points
-        a.c2_only = 1;
-      }
+      // g = dK .* e (e = -2 dk/dr2; = k for the squared exponential).  dK itself has one more reader, Q = dK^T C =
+      // Linv^T (Cbar^T C): that reduction takes Cbar instead (finish_layer applies Linv^T to the summed 256 x 256 result), so
+      // the stationary kernels never write dK: 2 GB per 10^6 points.  (The composite kernel differentiates dK directly.)
+      GemmArgs a = args_g(Pm, Mp, ctx->Cbar, y.Linv, ctx->Kbar, y.d.kernel_kind != DGP_KERNEL_MF ? (y.Et ? y.Et : y.Kt) : nullptr, ctx->Gt);
       RET(GX(ctx, 0, GEMM_NN, a, tri1, (double)Pl * Mp * 32));
     }
     // reductions over the chunk's points (accumulate into the all-reduce buffer)
@@ -690,19 +742,18 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       GemmArgs a = mk(Mp, Mp, Pl, y.Ct, Mp, y.Ct, Mp, acc + y.acc_G, Mp, 1.0, 1);
       a.batch = D; a.sC = MM; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp) * D, Pl, (long)Mp * 8);
       a.ascale = y.vbar; a.as_ld = D; a.ascale_mode = 2;
-      a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = ctx->gram_ws ? gemm_gram_ws_bytes() : 0;     // (Mp = 256: gemm_gram.h)
+      a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = ctx->gram_ws ? gemm_gram_ws_bytes(ctx->cu_count) : 0;     // (Mp = 256: gemm_gram.h)
       RET(GX(ctx, 0, GEMM_TN, a, tri1 * D, (double)Pl * Mp * 8));
     }
     {
       // Q' = Cbar^T C (stationary kernels; Q = Linv^T Q' in finish_layer) or Q = dK^T C (composite kernel: dK is stored)
       GemmArgs a = mk(Mp, Mp, Pl, y.d.kernel_kind != DGP_KERNEL_MF ? ctx->Cbar : ctx->Kbar, Mp, y.Ct, Mp, acc + y.acc_Q, Mp, 1.0, 1);
       a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp), Pl, (long)Mp * 16);
-      a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = ctx->gram_ws ? gemm_gram_ws_bytes() : 0;     // (Mp = 256: gemm_gram.h, two sources)
+      a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = ctx->gram_ws ? gemm_gram_ws_bytes(ctx->cu_count) : 0;     // (Mp = 256: gemm_gram.h, two sources)
       RET(GX(ctx, 0, GEMM_TN, a, tri1, (double)Pl * Mp * 16));
     }
     {
-      GemmArgs a = mk(Mp, D, Pl, y.Ct, Mp, y.mbar, D, acc + y.acc_du, D, 1.0, 1);
-      a.splits = pick_splits(ctx, Mp, D, Pl);
+      GemmArgs a = args_du(ctx, Pl, Mp, D, y.Ct, y.mbar, acc + y.acc_du);
       RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
     }
     }

@@ -104,6 +104,10 @@ struct GemmArgs {
   double* gram_ws = nullptr;   // scratch for gemm_gram.h's partial triangles (gram_ws_bytes >= gemm_gram_ws_bytes())
   long gram_ws_bytes = 0;
   int no_wide = 0;     // 1: keep this product on the 128 x 64 engine even where the wide-tile kernel (gemm_wide.h) applies
+  // the device this launch is for, as its context knows it (0: ask the runtime for the current device's CU count), and the
+  // CUs a persistent one-workgroup-per-CU kernel (wide-tile, tall-tile, Gram) leaves free for a collective that runs beside
+  // it (set per context by dgp_comm_init: state of the context, not of the process)
+  int cu_count = 0, reserve_cus = 0;
 };
 
 template <bool TA, bool TB, int BM, int BN, int BK, int WR, int WC, int VA, int VB>
@@ -724,9 +728,12 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 // Host-side dispatcher (defined in gemm_f64.hip)
 enum GemmOp : int { GEMM_NN = 0, GEMM_NT = 1, GEMM_TN = 2 };
 hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args);
+// which kernel family gemm_f64 selects for this call: 0 the 128 x 64 engine, 1 wide-tile, 2 tall-tile (T), 3 tall-tile (dC),
+// 4 weighted Gram, 5 one-workgroup small product (tests assert that a size reaches the kernel it is meant to check)
+int gemm_engine_of(GemmOp op, const GemmArgs& args);
 // CUs left free by the persistent kernels while a collective may run beside them (gemm_f64.hip)
-void gemm_reserve_cus(int n);
-int gemm_persistent_grid(int cus);
+int gemm_device_cus(const GemmArgs& a);                 // a.cu_count, else the current device's CU count
+int gemm_persistent_grid(const GemmArgs& a, int cus);   // workgroups of a one-per-CU kernel: cus less a.reserve_cus
 // one-workgroup products of the small models' chains (gemm_small.hip)
 bool gemm_small_ok(GemmOp op, const GemmArgs& a);
 hipError_t gemm_small(hipStream_t st, GemmOp op, const GemmArgs& a);
@@ -738,7 +745,7 @@ bool gemm_tallu_ok(const GemmArgs& a);
 hipError_t gemm_tallu(hipStream_t st, const GemmArgs& a);
 // weighted Gram products over the points (gemm_gram.h / gemm_gram.hip)
 bool gemm_gram_ok(const GemmArgs& a);
-long gemm_gram_ws_bytes();
+long gemm_gram_ws_bytes(int cu_count);      // cu_count <= 0: the current device
 hipError_t gemm_gram(hipStream_t st, const GemmArgs& a);
 
 }  // namespace dgp

@@ -163,26 +163,46 @@ static hipError_t dispatch(hipStream_t st, const GemmArgs& a) {
 // CUs the persistent kernels (one workgroup per CU: tall tiles, Gram) leave free.  A workgroup of theirs fills its CU, so
 // with one on every CU nothing else is scheduled until the kernel ends - which is fine for a single process (DESIGN.md
 // par. 10: the L2 sharing of a full grid is worth more than the free CUs) but makes a collective issued beside the
-// backward pass wait for the end of a kernel.  dgp_comm_init sets it.
-static int g_reserved_cus = 0;
-void gemm_reserve_cus(int n) { g_reserved_cus = n < 0 ? 0 : n; }
-int gemm_persistent_grid(int cus) {
+// backward pass wait for the end of a kernel.  dgp_comm_init sets it for its context (GemmArgs::reserve_cus).
+int gemm_device_cus(const GemmArgs& a) {
+  if (a.cu_count > 0) return a.cu_count;
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) return n;
+  return 256;
+}
+int gemm_persistent_grid(const GemmArgs& a, int cus) {
   if (cus < 64) return cus;
-  const int r = g_reserved_cus < cus / 4 ? g_reserved_cus : cus / 4;
+  const int want = a.reserve_cus < 0 ? 0 : a.reserve_cus;
+  const int r = want < cus / 4 ? want : cus / 4;
   return cus - r;
+}
+
+int gemm_engine_of(GemmOp op, const GemmArgs& args) {
+  GemmArgs a = args;
+  if (a.splits < 1) a.splits = 1;
+  if (a.batch < 1) a.batch = 1;
+  if (gemm_small_ok(op, a)) return 5;      // M, N, K <= 64: one workgroup, operands staged once
+  // row-panel products with a (block-)triangular or dense Mp-wide B: the tall-tile kernels, else the wide-tile kernel
+  if (op == GEMM_NN && !a.no_wide && gemm_tall_ok(a)) return 2;      // T = Ct * Wcat at Mp = 256: 256 x 128 tiles
+  if (op == GEMM_NN && !a.no_wide && gemm_tallu_ok(a)) return 3;     // dC = [2 vbar .* T] * W^T ... at Mp = 256, likewise
+  if (op == GEMM_NN && !a.no_wide && gemm_wide_ok(a)) return 1;
+  // weighted Gram products over the points (lower triangle, Mp = 256): the single-staging kernel of gemm_gram.h
+  if (op == GEMM_TN && !a.no_wide && gemm_gram_ok(a)) return 4;
+  return 0;
 }
 
 hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args) {
   GemmArgs a = args;
   if (a.splits < 1) a.splits = 1;
   if (a.batch < 1) a.batch = 1;
-  if (gemm_small_ok(op, a)) return gemm_small(st, op, a);      // M, N, K <= 64: one workgroup, operands staged once
-  // row-panel products with a (block-)triangular or dense Mp-wide B: the wide-tile kernel
-  if (op == GEMM_NN && !a.no_wide && gemm_tall_ok(a)) return gemm_tall(st, a);      // T = Ct * Wcat at Mp = 256: 256 x 128 tiles
-  if (op == GEMM_NN && !a.no_wide && gemm_tallu_ok(a)) return gemm_tallu(st, a);    // dC = [2 vbar .* T] * W^T ... at Mp = 256, likewise
-  if (op == GEMM_NN && !a.no_wide && gemm_wide_ok(a)) return gemm_wide(st, a);
-  // weighted Gram products over the points (lower triangle, Mp = 256): the single-staging kernel of gemm_gram.h
-  if (op == GEMM_TN && !a.no_wide && gemm_gram_ok(a)) return gemm_gram(st, a);
+  switch (gemm_engine_of(op, a)) {
+    case 5: return gemm_small(st, op, a);
+    case 2: return gemm_tall(st, a);
+    case 3: return gemm_tallu(st, a);
+    case 1: return gemm_wide(st, a);
+    case 4: return gemm_gram(st, a);
+    default: break;
+  }
   switch (op) {
     case GEMM_NN: return dispatch<false, false>(st, a);
     case GEMM_NT: return dispatch<false, true>(st, a);

@@ -39,19 +39,16 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramArgs g, int grid) 
   g.G[(long)d * 65536 + (long)(16 * r + 4 * (li >> 2) + lk) * 256 + 16 * c + 4 * (li & 3) + e] += sum;
 }
 
-static int gram_grid() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-    else cus = 256;
-    const char* e = getenv("DGP_GRAM_GRID");
-    if (e && atoi(e) > 0) cus = atoi(e);
-  }
-  return cus;
+static int gram_grid(int cu_count) {
+  static int grid_env = -1;
+  if (grid_env < 0) { const char* e = getenv("DGP_GRAM_GRID"); grid_env = (e && atoi(e) > 0) ? atoi(e) : 0; }
+  if (grid_env) return grid_env;
+  GemmArgs a;
+  a.cu_count = cu_count;
+  return gemm_device_cus(a);
 }
 
-long gemm_gram_ws_bytes() { return 2L * gram_grid() * GR_SLOT_BYTES; }
+long gemm_gram_ws_bytes(int cu_count) { return 2L * gram_grid(cu_count) * GR_SLOT_BYTES; }
 
 bool gemm_gram_ok(const GemmArgs& a) {
   static int enabled = -1;
@@ -74,7 +71,7 @@ bool gemm_gram_ok(const GemmArgs& a) {
   if (a.epi != 0 || a.rank != 0 || a.eadd != nullptr || a.C2 != nullptr || a.a_blocked || a.c_blocked || a.tri_row0 != 0) return false;
   if ((reinterpret_cast<uintptr_t>(a.A) & 15u) || (reinterpret_cast<uintptr_t>(a.B) & 15u) || (reinterpret_cast<uintptr_t>(a.C) & 7u)) return false;
   if (a.ascale && (reinterpret_cast<uintptr_t>(a.ascale) & 15u)) return false;
-  if (a.gram_ws == nullptr || a.gram_ws_bytes < gemm_gram_ws_bytes() || (reinterpret_cast<uintptr_t>(a.gram_ws) & 31u)) return false;
+  if (a.gram_ws == nullptr || a.gram_ws_bytes < gemm_gram_ws_bytes(a.cu_count) || (reinterpret_cast<uintptr_t>(a.gram_ws) & 31u)) return false;
   return true;
 }
 
@@ -87,7 +84,7 @@ hipError_t gemm_gram(hipStream_t st, const GemmArgs& a) {
   g.ws = a.gram_ws;
   g.P = a.K;
   g.D = a.batch;
-  const unsigned grid = (unsigned)gemm_persistent_grid(gram_grid());          // (K >= min_k: every workgroup has k-tiles; the scratch is sized for the full grid)
+  const unsigned grid = (unsigned)gemm_persistent_grid(a, gram_grid(a.cu_count));          // (K >= min_k: every workgroup has k-tiles; the scratch is sized for the full grid)
   if (g.A) hipLaunchKernelGGL((gemm_gram_kernel<false, 2>), dim3(grid), dim3(512), 0, st, g);
   else if (g.s) hipLaunchKernelGGL((gemm_gram_kernel<true, 1>), dim3(grid), dim3(512), 0, st, g);
   else hipLaunchKernelGGL((gemm_gram_kernel<false, 1>), dim3(grid), dim3(512), 0, st, g);

@@ -21,14 +21,9 @@ bool gemm_tall_ok(const GemmArgs& a) {
 }
 
 hipError_t gemm_tall(hipStream_t st, const GemmArgs& a) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-    else cus = 256;
-    const char* e = getenv("DGP_TALL_GRID");
-    if (e && atoi(e) > 0) cus = atoi(e);
-  }
+  static int grid_env = -1;
+  if (grid_env < 0) { const char* e = getenv("DGP_TALL_GRID"); grid_env = (e && atoi(e) > 0) ? atoi(e) : 0; }
+  const int cus = grid_env ? grid_env : gemm_device_cus(a);
   TallArgs g;
   g.A = a.A; g.lda = a.lda;
   g.B = a.B; g.ldb = a.ldb;
@@ -36,7 +31,7 @@ hipError_t gemm_tall(hipStream_t st, const GemmArgs& a) {
   g.rowsq = a.rowsq; g.rowsq_ld = a.rowsq_ld;
   g.M = a.M; g.D = (int)(a.N / 256);
   const long ntile = ((a.M + 255) / 256) * g.D;
-  const long gmax = gemm_persistent_grid(cus);
+  const long gmax = gemm_persistent_grid(a, cus);
   const unsigned grid = (unsigned)(ntile < gmax ? ntile : gmax);
   if (g.C) hipLaunchKernelGGL(gemm_tall_kernel<true>, dim3(grid), dim3(512), 0, st, g);
   else hipLaunchKernelGGL(gemm_tall_kernel<false>, dim3(grid), dim3(512), 0, st, g);

@@ -30,14 +30,9 @@ bool gemm_tallu_ok(const GemmArgs& a) {
 }
 
 hipError_t gemm_tallu(hipStream_t st, const GemmArgs& a) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-    else cus = 256;
-    const char* e = getenv("DGP_TALL_GRID");
-    if (e && atoi(e) > 0) cus = atoi(e);
-  }
+  static int grid_env = -1;
+  if (grid_env < 0) { const char* e = getenv("DGP_TALL_GRID"); grid_env = (e && atoi(e) > 0) ? atoi(e) : 0; }
+  const int cus = grid_env ? grid_env : gemm_device_cus(a);
   TallUArgs g;
   g.A = a.A; g.lda = a.lda;
   g.B = a.B; g.ldb = a.ldb;
@@ -49,7 +44,7 @@ hipError_t gemm_tallu(hipStream_t st, const GemmArgs& a) {
   g.alpha = a.alpha;
   g.M = a.M; g.D = (int)(a.K / 256);
   const long nb = (a.M + 255) / 256;
-  const long gmax = gemm_persistent_grid(cus);
+  const long gmax = gemm_persistent_grid(a, cus);
   const unsigned grid = (unsigned)(nb < gmax ? nb : gmax);
   if (a.rank == 8) hipLaunchKernelGGL(gemm_tallu_kernel<8>, dim3(grid), dim3(512), 0, st, g);
   else if (a.rank > 0) hipLaunchKernelGGL(gemm_tallu_kernel<-1>, dim3(grid), dim3(512), 0, st, g);

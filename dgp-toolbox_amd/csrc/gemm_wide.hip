@@ -58,16 +58,11 @@ bool gemm_wide_ok(const GemmArgs& a) {
 }
 
 hipError_t gemm_wide(hipStream_t st, const GemmArgs& a) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-    else cus = 256;
-    const char* e = getenv("DGP_WIDE_GRID");
-    if (e && atoi(e) > 0) cus = atoi(e);
-  }
+  static int grid_env = -1;
+  if (grid_env < 0) { const char* e = getenv("DGP_WIDE_GRID"); grid_env = (e && atoi(e) > 0) ? atoi(e) : 0; }
+  const int cus = grid_env ? grid_env : gemm_device_cus(a);
   const long tiles = (a.M / WBM) * (a.N / WBN);
-  long gmax = gemm_persistent_grid(cus); // one persistent workgroup per CU (147 KB of LDS each), less those left to a collective
+  long gmax = gemm_persistent_grid(a, cus); // one persistent workgroup per CU (147 KB of LDS each), less those left to a collective
   // With several 256-column tiles per triangular block the tiles of a row panel cost 1 : 2.8 (diagonal block only /
   // diagonal + dense).  A workgroup walks tiles b, b + grid, ...: with grid a multiple of the tiles per panel it would
   // see one kind only.  8 * 31 workgroups make its column tile cycle through all of them.

@@ -22,8 +22,9 @@ SYMBOLS = [
     "dgp_params_get", "dgp_params_set", "dgp_data_set", "dgp_set_workspace_limit", "dgp_batch_set", "dgp_elbo", "dgp_propagate",
     "dgp_propagate_vjp", "dgp_vjp_accumulate", "dgp_propagate_full_cov", "dgp_gpr_lml", "dgp_gpr_predict", "dgp_gpr_predict_vjp",
     "dgp_grad_partial", "dgp_acc_info", "dgp_acc_bind", "dgp_grad_finish", "dgp_grad_get", "dgp_last_elbo", "dgp_grad_step",
-    "dgp_comm_unique_id", "dgp_comm_init", "dgp_comm_destroy", "dgp_comm_allreduce",
-    "dgp_adam_reset", "dgp_adam_step", "dgp_adam_iterations", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_dev_gemm", "dgp_dev_gram",
+    "dgp_comm_available", "dgp_comm_unique_id", "dgp_comm_init", "dgp_comm_destroy", "dgp_comm_allreduce",
+    "dgp_adam_reset", "dgp_adam_step", "dgp_adam_iterations", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_prof_mark", "dgp_prof_marks_read", "dgp_dev_gemm", "dgp_dev_gram",
+    "dgp_dev_layer_products",
     "dgp_dev_chol", "dgp_dev_trinv", "dgp_dev_normals", "dgp_dev_mfma_peak",
 ]
 
@@ -91,6 +92,7 @@ def load():
         "dgp_grad_get": (C.c_int, [vp, _dp]),
         "dgp_last_elbo": (C.c_int, [vp, _dp]),
         "dgp_grad_step": (C.c_int, [vp, i32, u64, _dpp, _dp]),
+        "dgp_comm_available": (C.c_int, []),
         "dgp_comm_unique_id": (C.c_int, [vp]),
         "dgp_comm_init": (C.c_int, [vp, i32, i32, vp]),
         "dgp_comm_destroy": (C.c_int, [vp]),
@@ -102,8 +104,11 @@ def load():
                                           i32, _dp]),
         "dgp_prof_enable": (C.c_int, [vp, i32]),
         "dgp_prof_read": (C.c_int, [vp, i32, _dp, C.POINTER(i64), _dp, _dp]),
+        "dgp_prof_mark": (C.c_int, [vp]),
+        "dgp_prof_marks_read": (C.c_int, [vp, i32, _dp, C.POINTER(i32)]),
         "dgp_dev_gemm": (C.c_int, [vp, i32, i64, i64, i64, _dp, i64, _dp, i64, _dp, i64, dbl, i32, i32, i32, i64, i32, _dp]),
         "dgp_dev_gram": (C.c_int, [vp, _dp, _dp, i64, i32, _dp]),
+        "dgp_dev_layer_products": (C.c_int, [vp, i64, i32, i32] + [_dp] * 14 + [C.POINTER(i32)]),
         "dgp_dev_chol": (C.c_int, [vp, _dp, i32, i32]),
         "dgp_dev_trinv": (C.c_int, [vp, _dp, _dp, i32, i32]),
         "dgp_dev_normals": (C.c_int, [vp, u64, i32, i32, i64, i64, i32, _dp]),
@@ -329,6 +334,11 @@ class Context:
 
     # ---- multi-GPU: library-owned RCCL communicator ---------------------------------------------
     @staticmethod
+    def comm_available():
+        """True when librccl.so loads with every entry point the library binds (no communicator is created)."""
+        return load().dgp_comm_available() == DGP_OK
+
+    @staticmethod
     def comm_unique_id():
         """128 bytes (ncclUniqueId) from rank 0, to be broadcast to the other ranks by the host."""
         lib = load()
@@ -411,6 +421,17 @@ class Context:
         names = ["mfma_contractions", "per_point_streaming", "small_matrix_chain", "adam"]
         return {n: {"ms": ms[i], "launches": int(ln[i]), "alg_flops": fl[i], "alg_bytes": by[i]} for i, n in enumerate(names)}
 
+    def prof_mark(self):
+        """Record a step boundary (HIP event) on the context's stream."""
+        self._chk(self._lib.dgp_prof_mark(self._h))
+
+    def prof_marks_read(self, n_max=65536):
+        """Milliseconds between consecutive marks (synchronises on the last mark, clears the marks)."""
+        out = np.zeros(int(n_max))
+        n = C.c_int32()
+        self._chk(self._lib.dgp_prof_marks_read(self._h, int(n_max), _ptr(out), C.byref(n)))
+        return out[:n.value].copy()
+
     # ---- unit-level hooks -------------------------------------------------------------------
     def dev_gemm(self, op, A, B, C0=None, alpha=1.0, beta=0, splits=1, tri=0, triblk=0, repeats=0):
         A, B = _c(A), _c(B)
@@ -432,6 +453,25 @@ class Context:
         sp = None if s is None else _c(s)
         self._chk(self._lib.dgp_dev_gram(self._h, _ptr(Cmat), None if sp is None else _ptr(sp), Cmat.shape[0], D, _ptr(G)))
         return G
+
+    ENGINES = {0: "engine128x64", 1: "wide", 2: "tall", 3: "tallu", 4: "gram", 5: "small"}
+
+    def dev_layer_products(self, Kt, Linv, Wcat, u, vbar, mbar):
+        """The point contractions of one SVGP layer (dgp_dev_layer_products) on explicit operands: Kt [P, Mp], Linv [Mp, Mp]
+        lower, Wcat [Mp, D*Mp], u [Mp, D], vbar / mbar [P, D].  Returns a dict of Ct, cn, T, tn, mean0, Cbar, g, du and
+        `engines`: the kernel family that ran (Ct, T, Cbar, g, du)."""
+        Kt, Linv, Wcat, u, vbar, mbar = (_c(a) for a in (Kt, Linv, Wcat, u, vbar, mbar))
+        P, Mp = Kt.shape
+        D = u.shape[1]
+        assert Linv.shape == (Mp, Mp) and Wcat.shape == (Mp, D * Mp) and vbar.shape == (P, D) and mbar.shape == (P, D)
+        out = {"Ct": np.empty((P, Mp)), "cn": np.empty(P), "T": np.empty((P, D * Mp)), "tn": np.empty((P, D)),
+               "mean0": np.empty((P, D)), "Cbar": np.empty((P, Mp)), "g": np.empty((P, Mp)), "du": np.empty((Mp, D))}
+        eng = (C.c_int32 * 5)()
+        self._chk(self._lib.dgp_dev_layer_products(self._h, P, Mp, D, _ptr(Kt), _ptr(Linv), _ptr(Wcat), _ptr(u), _ptr(vbar),
+                                                   _ptr(mbar), *[_ptr(out[k]) for k in ("Ct", "cn", "T", "tn", "mean0", "Cbar", "g", "du")],
+                                                   eng))
+        out["engines"] = [self.ENGINES[int(e)] for e in eng]
+        return out
 
     def dev_chol(self, A):
         A = _c(A).copy()

@@ -105,23 +105,28 @@ class DGP_Base:
                 # the library owns an RCCL communicator: rank 0's unique id travels through the process group once.
                 # Every rank must end up on the same path, so a failure anywhere (librccl not loadable, init error) is
                 # agreed on through the group and all ranks keep the process group's collective instead.
-                ok = 1.0
-                try:
-                    uid = _native.Context.comm_unique_id() if self._dist.rank == 0 else bytes(128)
-                except Exception as e:           # noqa: BLE001
-                    uid, ok = bytes(128), 0.0
-                    self._say_err(f"dgp_comm_unique_id failed ({e}); using the process group's all-reduce")
-                uid = self._dist.broadcast_bytes(uid, dev)
+                # Every step is agreed on through the group BEFORE the collective ncclCommInitRank: (1) librccl loads and
+                # has every symbol on every rank, (2) rank 0 obtained a unique id.
+                ok = 1.0 if _native.Context.comm_available() else 0.0
+                if ok < 0.5:
+                    self._say_err("librccl.so not loadable here; using the process group's all-reduce")
                 if self._dist.all_reduce_min(ok, dev) > 0.5:
                     try:
-                        self._ctx.comm_init(self._dist.rank, self._dist.world, uid)
-                    except Exception as e:       # noqa: BLE001
-                        ok = 0.0
-                        self._say_err(f"dgp_comm_init failed ({e}); using the process group's all-reduce")
+                        uid = _native.Context.comm_unique_id() if self._dist.rank == 0 else bytes(128)
+                    except Exception as e:           # noqa: BLE001
+                        uid, ok = bytes(128), 0.0
+                        self._say_err(f"dgp_comm_unique_id failed ({e}); using the process group's all-reduce")
+                    uid = self._dist.broadcast_bytes(uid, dev)
                     if self._dist.all_reduce_min(ok, dev) > 0.5:
-                        self._native_comm = True
-                    else:
-                        self._ctx.comm_destroy()
+                        try:
+                            self._ctx.comm_init(self._dist.rank, self._dist.world, uid)
+                        except Exception as e:       # noqa: BLE001
+                            ok = 0.0
+                            self._say_err(f"dgp_comm_init failed ({e}); using the process group's all-reduce")
+                        if self._dist.all_reduce_min(ok, dev) > 0.5:
+                            self._native_comm = True
+                        else:
+                            self._ctx.comm_destroy()
         return self._ctx
 
     def _sync_model(self):

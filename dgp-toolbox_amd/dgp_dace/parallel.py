@@ -98,13 +98,12 @@ class Dist:
         self.dist.barrier()
 
     def native_comm(self):
-        """True when the library should own the collective (dgp_comm_init, RCCL on its own streams): the `nccl` backend
-        unless DGP_COMM=torch.  With gloo (CPU tests, one-GPU rehearsals) the reduce stays in torch.distributed unless
-        DGP_COMM=native asks for the library's communicator there too."""
-        mode = os.environ.get("DGP_COMM", "auto")      # auto | native (also under gloo: rehearsals) | torch
-        if mode == "native":
-            return self.on_gpu
-        return mode != "torch" and self.dist.get_backend() == "nccl"
+        """True when the library should own the collective (dgp_comm_init: RCCL on the library's comm stream, per-layer
+        all-reduces overlapped with the backward pass).  Opt-in with DGP_COMM=native (any backend with device tensors):
+        the default is the process group's own all-reduce (`torch`), because the library-owned communicator has only ever
+        run with one rank on the boxes this was built on - a multi-rank run must be recorded before it becomes the default."""
+        mode = os.environ.get("DGP_COMM", "torch")      # torch (default) | native
+        return mode == "native" and self.on_gpu
 
     def broadcast_bytes(self, payload, dev):
         """Rank 0's `payload` (bytes) on every rank, through the process group (a uint8 tensor on the group's device)."""

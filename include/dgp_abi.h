@@ -172,7 +172,11 @@ int dgp_grad_step(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* z
  *   dgp_comm_unique_id : rank 0 fills 128 bytes (ncclUniqueId); the host broadcasts them to the other ranks
  *   dgp_comm_init      : every rank, same id; world == 1 with id128 == NULL creates no communicator (nothing to reduce),
  *                        world == 1 with an id creates a one-rank communicator (exercises the RCCL path on one GPU)
- *   dgp_comm_allreduce : in-place sum of n doubles at a DEVICE pointer, on the context's stream (test / utility)      */
+ *   dgp_comm_allreduce : in-place sum of n doubles at a DEVICE pointer, on the context's stream (test / utility)
+ *   dgp_comm_available : 0 when librccl.so can be loaded and has every entry point the library binds.  EVERY rank calls it
+ *                        and the ranks agree on the answers BEFORE any of them calls dgp_comm_init (ncclCommInitRank is
+ *                        collective: a rank that cannot join would leave the others waiting)                              */
+int dgp_comm_available(void);
 int dgp_comm_unique_id(void* id128_out);
 int dgp_comm_init(dgp_ctx* ctx, int32_t rank, int32_t world, const void* id128);
 int dgp_comm_destroy(dgp_ctx* ctx);
@@ -205,6 +209,12 @@ int dgp_prof_enable(dgp_ctx* ctx, int32_t on);
 int dgp_prof_read(dgp_ctx* ctx, int32_t n_cat, double* ms_out, int64_t* launches_out, double* alg_flops_out,
                   double* alg_bytes_out);   /* synchronises, returns totals since enable, then resets */
 
+/* Step boundaries: dgp_prof_mark records a HIP event on the context's stream (no synchronisation); dgp_prof_marks_read waits
+ * for the last one, returns the milliseconds between consecutive marks (n_marks - 1 intervals, at most n_max) and clears
+ * them.  bench.py brackets every iteration with marks and reports the median interval.           */
+int dgp_prof_mark(dgp_ctx* ctx);
+int dgp_prof_marks_read(dgp_ctx* ctx, int32_t n_max, double* ms_between_out, int32_t* n_out);
+
 /* ---- unit-level entry points (used by tests/ to check single kernels against NumPy) -------------
  * dgp_dev_gemm: C = alpha op(A) op(B) (+ C if beta) on the engine the shapes select (128 x 64 engine, wide-tile kernel,
  * weighted Gram kernel).  The same host pointer for A and B (equal shapes) is uploaded ONCE and used as both operands:
@@ -217,6 +227,19 @@ int dgp_dev_gemm(dgp_ctx* ctx, int32_t op /*0 NN,1 NT,2 TN*/, int64_t M, int64_t
  * the reduction  G_d = sum_p vbar_pd c_p c_p^T  of SURVEY App. C step 2 on its own. */
 int dgp_dev_gram(dgp_ctx* ctx, const double* C /* [P,256] */, const double* s /* [P,D] or NULL */, int64_t P, int32_t D,
                  double* G /* [D,256,256], in/out */);
+/* The point contractions of ONE SVGP layer on caller-supplied operands, issued through the same argument builders as the
+ * forward / backward pass (csrc/dgp_ctx.h: args_Ct, args_T, args_mean0, args_Cbar, args_g, args_du), so that a size selects the
+ * kernel it selects in training (128 x 64 engine, wide-tile, tall-tile): layers.py:243-263 in whitened form and its
+ * adjoint.  Mp a multiple of 64, Linv lower triangular, Wcat = [W_0 | ... | W_{D-1}], W_d lower.
+ *   Ct   = Kt Linv^T                                  cn[p]    = |c_p|^2
+ *   T_d  = Ct W_d   (returned row-major [P, D*Mp])    tn[p][d] = |t_pd|^2        mean0 = Ct u
+ *   Cbar = sum_d 2 vbar_pd (T_d W_d^T - Ct) + mbar u^T
+ *   g    = (Cbar Linv) .* Kt                          du = Ct^T mbar
+ * engines[5] (may be NULL): the kernel family (gemm_engine_of) that ran Ct, T, Cbar, g, du.                          */
+int dgp_dev_layer_products(dgp_ctx* ctx, int64_t P, int32_t Mp, int32_t D, const double* Kt, const double* Linv,
+                           const double* Wcat, const double* u, const double* vbar, const double* mbar, double* Ct,
+                           double* cn, double* T, double* tn, double* mean0, double* Cbar, double* g, double* du,
+                           int32_t* engines);
 int dgp_dev_chol(dgp_ctx* ctx, double* A, int32_t M, int32_t batch);            /* in place, lower */
 int dgp_dev_trinv(dgp_ctx* ctx, const double* L, double* X, int32_t M, int32_t batch);
 int dgp_dev_normals(dgp_ctx* ctx, uint64_t seed, int32_t layer, int32_t S, int64_t n0, int64_t N, int32_t D,

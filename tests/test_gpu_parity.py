@@ -222,7 +222,9 @@ def test_grad_step_equals_partial_reduce_finish():
     assert abs(e3 - e0) <= 1e-13 * abs(e0)
     np.testing.assert_allclose(ctx.grad_get(), g0, rtol=1e-12, atol=1e-12 * np.abs(g0).max())
     import torch
+    assert Context.comm_available()
     t = torch.arange(1000, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()              # `t` is filled on torch's stream, the all-reduce runs on the context's own
     ctx.comm_allreduce(t.data_ptr(), t.numel())
     ctx.sync()
     assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
@@ -1266,17 +1268,21 @@ def test_full_cov_beyond_1024_points():
     _close(np.einsum("siid->sid", np.asarray(Fv[0])), Fv_d[0], rtol=1e-8, atol=1e-10)
 
 
-TALL_WORKER = r'''
-import sys, io, contextlib, hashlib
+PROD_WORKER = r"""
+import sys, io, contextlib
 import numpy as np
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/dgp-toolbox_amd")
-from bench import synthetic
 from dgp_dace.gpflow_compat import RBF, Gaussian
 from dgp_dace.models.dgp import DGP
-N, D, M, S = 10176, 8, 256, 10      # 101760 rows = 795 x 128: the last 256-row tile is half empty
-X, Y, Z = synthetic(N, D, M)
+st = np.load(STATE)
+X, Y, Z, S, seed = st["X"], st["Y"], st["Z"], int(st["S"]), int(st["seed"])
+D = X.shape[1]
 with contextlib.redirect_stdout(io.StringIO()):
     m = DGP(X, Y, Z, [RBF(1.0, [1.0] * D) for _ in range(3)], [8, 8], Gaussian(), num_samples=S)
+m.likelihood.likelihood.variance.assign(st["lik_variance"])
+for i, l in enumerate(m.layers):
+    l.kern.variance.assign(st[f"L{i}_variance"]); l.kern.lengthscales.assign(st[f"L{i}_lengthscales"])
+    l.q_mu.assign(st[f"L{i}_q_mu"]); l.q_sqrt.assign(st[f"L{i}_q_sqrt"])
 ctx = m._sync_model()
 m._sync_data(m.data)
 if COMM:
@@ -1284,35 +1290,84 @@ if COMM:
     # (grids of 248 workgroups: other partial-sum boundaries in the Gram kernel, other tile-to-workgroup maps)
     from dgp_dace._native import Context
     ctx.comm_init(0, 1, Context.comm_unique_id())
-    e = ctx.grad_step(S, 5, None, want_elbo=True)
+    e = ctx.grad_step(S, seed, None, want_elbo=True)
 else:
-    ctx.grad_partial(S, 5, None)
+    ctx.grad_partial(S, seed, None)
     e = ctx.grad_finish(want_elbo=True)
 g = ctx.grad_get()
-np.savez(OUT, elbo=e, grad=g)
-'''
+Fs, Fm, Fv = ctx.propagate(X, S, seed)          # forward-only path (same Philox normals), every layer, every point
+np.savez(OUT, elbo=e, grad=g, **{f"Fm{i}": a for i, a in enumerate(Fm)}, **{f"Fv{i}": a for i, a in enumerate(Fv)},
+         **{f"Fs{i}": a for i, a in enumerate(Fs)})
+"""
 
 
-def test_tall_tile_kernels_against_the_wide_tile_kernel(tmp_path):
-    """The forward product t_d = W_d^T c (gemm_tall.h) and the backward product dC = sum_d [2 vbar_d .* t_d] W_d^T - .. c
-    + mbar u^T (gemm_tallu.h) on 256 x 128 tiles add the same k-tiles in the same order as the wide-tile kernel they
-    replace (T and dC themselves are bit-identical, tools/wide_bench); only the partial row sums |t_d|^2 are added in
-    another order.  ELBO and gradient of a config-2-shaped model (M = 256, D = 8, 101760 sample points) must therefore
-    agree to rounding between DGP_TALL=DGP_TALLU=1 (default) and 0, and with a communicator attached (persistent grids
-    of 248 instead of 256 workgroups, dgp_grad_step).  The switches are read once per process, hence the child processes
-    (one after the other)."""
+def test_config2_shape_production_kernels_against_the_oracle(tmp_path):
+    """BASELINE config 2's shape (M = 256, D = 8, S = 10, num_units [8, 8]) with N = 10 176 data points: 101 760 sample rows =
+    795 x 128, i.e. the sizes at which the headline run's kernels are selected - wide-tile `Ct` (>= 98 304 rows), tall-tile
+    `T` and `dC` (256 x 128 tiles, the last 256-row tile half empty), the weighted Gram kernel (>= 8192 points) - and the
+    oracle is still affordable.  Compared with the restatement of R/dgp_dace/utils/layers.py:243-276 and
+    R/dgp_dace/models/dgp.py:89-100,272-275 (oracle/dgp_oracle.py forward, dgp_oracle_torch.py autograd) with the same
+    Philox normals, in a non-trivial state (random q_mu: the rank term mbar u^T is live; perturbed q_sqrt, lengthscales,
+    variances):  ELBO <= 1e-9 relative, EVERY gradient block <= 1e-7 of its largest entry, Fmean / Fvar of every layer at
+    every point and sample.  Three runs (the kernel switches are read once per process, hence child processes, one after
+    the other): defaults; DGP_TALL = DGP_TALLU = 0 (the wide-tile kernel's `T` / `dC` modes); defaults with a one-rank RCCL
+    communicator attached (248-workgroup persistent grids, dgp_grad_step)."""
     import subprocess, sys, os
+    import dgp_oracle_torch as T
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import synthetic
+    N, D, M, S, seed = 10176, 8, 256, 10, 5
+    X, Y, Z = synthetic(N, D, M)
+    rng = np.random.default_rng(11)
+    dims = [D, 8, 8]
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(1.0, np.ones(d)) for d in dims], [8, 8], num_samples=S)
+    state = {"X": X, "Y": Y, "Z": Z, "S": S, "seed": seed}
+    mo.lik_variance = 0.7
+    state["lik_variance"] = mo.lik_variance
+    for i, l in enumerate(mo.layers):
+        Mq, Dq = l.q_mu.shape
+        l.kern.variance = float(rng.uniform(0.8, 1.5))
+        l.kern.lengthscales = rng.uniform(0.9, 1.6, size=l.kern.lengthscales.shape)
+        l.q_mu = 0.3 * rng.standard_normal((Mq, Dq))
+        l.q_sqrt = np.tril(l.q_sqrt * (0.1 if i < 2 else 1.0) + 0.01 * rng.standard_normal(l.q_sqrt.shape))
+        state[f"L{i}_variance"] = l.kern.variance; state[f"L{i}_lengthscales"] = l.kern.lengthscales
+        state[f"L{i}_q_mu"] = l.q_mu; state[f"L{i}_q_sqrt"] = l.q_sqrt
+    spath = str(tmp_path / "state.npz")
+    np.savez(spath, **state)
     res = []
     for flag, comm in (("1", False), ("0", False), ("1", True)):
-        out = str(tmp_path / f"tall{flag}{int(comm)}.npz")
-        code = f"ROOT={root!r}\nOUT={out!r}\nCOMM={comm!r}\n" + TALL_WORKER
+        out = str(tmp_path / f"prod{flag}{int(comm)}.npz")
+        code = f"ROOT={root!r}\nOUT={out!r}\nSTATE={spath!r}\nCOMM={comm!r}\n" + PROD_WORKER
         env = dict(os.environ, DGP_TALL=flag, DGP_TALLU=flag)
         p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                           timeout=600)
+                           timeout=900)
         assert p.returncode == 0, p.stdout
-        res.append(np.load(out))
+        res.append(dict(np.load(out)))
+    # the oracle: forward per layer (NumPy), ELBO + every gradient (torch autograd), chunked over the points
+    zs = O.draw_zs(mo, seed, S, N)
+    oFs, oFm, oFv = mo.propagate(X, S, zs)
+    eo, G = T.elbo_and_grads(mo, zs, chunk=2544)
+    names = ["Z", "variance", "lengthscales", "q_mu", "q_sqrt"]
+    for k, r in enumerate(res):
+        assert abs(float(r["elbo"]) - eo) <= 1e-9 * abs(eo), (k, float(r["elbo"]), eo)
+        off = 0
+        for i, l in enumerate(mo.layers):
+            for nm in names:
+                ref = np.asarray(G["layers"][i][nm], dtype=np.float64)
+                got = r["grad"][off:off + ref.size].reshape(ref.shape)
+                off += ref.size
+                if nm == "q_sqrt":
+                    got = np.tril(got)
+                assert np.abs(got - ref).max() <= 1e-7 * np.abs(ref).max(), (k, i, nm, np.abs(got - ref).max(), np.abs(ref).max())
+        ref = float(G["lik_variance"])
+        assert abs(r["grad"][off] - ref) <= 1e-7 * abs(ref), (k, "lik")
+        assert off + 1 == r["grad"].size
+        for i in range(3):       # per element, all 101 760 rows (layer 0: the N distinct inputs, S times)
+            _close(r[f"Fm{i}"], np.asarray(oFm[i]), rtol=1e-7, atol=1e-9)
+            _close(r[f"Fv{i}"], np.asarray(oFv[i]), rtol=1e-7, atol=1e-9)
+            _close(r[f"Fs{i}"], np.asarray(oFs[i]), rtol=1e-6, atol=1e-8)
+    # and among themselves: the tall tiles add the same k-tiles in the same order as the wide-tile kernel they replace
     for k in (0, 2):
         assert abs(float(res[k]["elbo"]) - float(res[1]["elbo"])) < 1e-13 * abs(float(res[1]["elbo"]))
         np.testing.assert_allclose(res[k]["grad"], res[1]["grad"], rtol=0, atol=1e-12 * np.abs(res[1]["grad"]).max())
-    assert np.isfinite(res[0]["grad"]).all() and np.abs(res[0]["grad"]).max() > 0

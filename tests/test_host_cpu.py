@@ -442,3 +442,25 @@ def test_utils_surface_reparameterize_and_broadcasting_likelihood():
     np.testing.assert_allclose(lik.predict_density(mean, var, Y), -0.5 * np.log(2 * np.pi * (var + 0.3)) - 0.5 * (Y[None] - mean) ** 2 / (var + 0.3))
     assert lik.conditional_variance(mean).shape == (S, N, D) and np.allclose(lik.conditional_variance(mean), 0.3)
     assert lik.needs_broadcasting is False
+
+
+def test_mfma_hazard_gate_is_part_of_the_build():
+    """The kernels with inline-asm MFMAs (gemm_gram.h, gemm_tall.h, gemm_tallu.h) are scanned for a VALU write of an MFMA
+    operand right in front of the MFMA - a hazard hipcc cannot see through the asm statement and that once produced
+    single wrong accumulator elements.  (1) the scanner flags a synthetic hazard and accepts the separated form;
+    (2) `make` runs it on the kept gfx950 assembly and leaves its stamp only when it found nothing."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "dgp-toolbox_amd", "csrc"))
+    import check_mfma_hazard as H
+    hazard = ["v_mov_b64 v[10:11], 0", "v_mfma_f64_4x4x4_4b_f64 v[10:11], v[2:3], v[4:5], v[10:11]"]
+    n, found = H.scan(hazard)
+    assert n == 1 and len(found) == 1
+    n, found = H.scan([hazard[0], "s_nop 1", hazard[1]])
+    assert n == 1 and not found
+    n, found = H.scan(["v_mul_f64 v[2:3], v[2:3], v[8:9]", "ds_read_b128 v[20:23], v30", hazard[1]])      # A operand, one slot
+    assert len(found) == 1
+    csrc = os.path.join(ROOT, "dgp-toolbox_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "-j8"], stdout=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(csrc, "build", ".hazard_ok"))
+    asms = [os.path.join(csrc, "build", f"{k}-hip-amdgcn-amd-amdhsa-gfx950.s") for k in ("gemm_gram", "gemm_tall", "gemm_tallu")]
+    assert H.main(asms) == 0

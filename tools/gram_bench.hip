@@ -37,7 +37,7 @@ static float time_ms(hipStream_t st, int reps, const std::function<void()>& f) {
 static double* g_ws = nullptr;
 static GemmArgs gram_args(const double* Ct, const double* s, double* G, long P, int D, bool weighted) {
   GemmArgs a{};
-  a.gram_ws = g_ws; a.gram_ws_bytes = gemm_gram_ws_bytes();
+  a.gram_ws = g_ws; a.gram_ws_bytes = gemm_gram_ws_bytes(0);
   a.A = Ct; a.B = Ct; a.C = G;
   a.lda = a.ldb = a.ldc = 256;
   a.M = a.N = 256; a.K = P;
@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
   double* Ct = dalloc((size_t)Pmax * 256);
   double* s = dalloc((size_t)Pmax * 16);
   double* G0 = dalloc(16 * 65536), *G1 = dalloc(16 * 65536);
-  g_ws = dalloc(gemm_gram_ws_bytes() / 8);
+  g_ws = dalloc(gemm_gram_ws_bytes(0) / 8);
   fill_rand(Ct, (size_t)Pmax * 256, 1);
   fill_rand(s, (size_t)Pmax * 16, 2);
   int bad = 0;
