@@ -334,13 +334,26 @@ class Context:
 
     # ---- multi-GPU: library-owned RCCL communicator ---------------------------------------------
     @staticmethod
+    def _rccl_first_from_torch():
+        """The library binds RCCL with dlopen("librccl.so.1"): the process's copy when one is loaded already.  torch ships
+        its own librccl; if the library loaded the system copy FIRST and torch came later, the process would hold two RCCL
+        runtimes (seen as `double free or corruption` at exit).  So torch, when installed, is imported before the first
+        dlopen."""
+        try:
+            import torch  # noqa: F401
+        except Exception:      # noqa: BLE001   (no torch: the system librccl is the only copy)
+            pass
+
+    @staticmethod
     def comm_available():
         """True when librccl.so loads with every entry point the library binds (no communicator is created)."""
+        Context._rccl_first_from_torch()
         return load().dgp_comm_available() == DGP_OK
 
     @staticmethod
     def comm_unique_id():
         """128 bytes (ncclUniqueId) from rank 0, to be broadcast to the other ranks by the host."""
+        Context._rccl_first_from_torch()
         lib = load()
         buf = C.create_string_buffer(128)
         rc = lib.dgp_comm_unique_id(C.cast(buf, C.c_void_p))
@@ -349,6 +362,8 @@ class Context:
         return bytes(buf.raw)
 
     def comm_init(self, rank, world, unique_id=None):
+        if unique_id is not None:
+            self._rccl_first_from_torch()
         buf = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
         self._chk(self._lib.dgp_comm_init(self._h, int(rank), int(world), C.cast(buf, C.c_void_p) if buf is not None else None))
         self.comm_world = int(world)
