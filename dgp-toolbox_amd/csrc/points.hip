@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void rbf_kuf_kernel(const double* __restrict__
   const double v0 = var[0];
   const long p0 = (long)blockIdx.x * pts_per_block;
   const long p1 = min(P, p0 + pts_per_block);
+#pragma unroll 2
   for (long p = p0; p < p1; ++p) {
     const double* __restrict__ x = Xin + (x_row0 + p) * din;       // uniform address: scalar loads
     double r2 = 0.0;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void rbf_kuf_kernel(const double* __restrict__
     }
     if (m < Mp) {
       if (kind == 0) {
-        Kt[p * Mp + m] = (m < M) ? v0 * exp(-0.5 * r2) : 0.0;
+        Kt[p * Mp + m] = (m < M) ? v0 * exp_nonpos(-0.5 * r2) : 0.0;
       } else {
         double k, e;
         stationary_k(kind, v0, r2, k, e);
@@ -110,9 +111,86 @@ __global__ __launch_bounds__(256) void rbf_kuf_kernel(const double* __restrict__
   }
 }
 
+// The same for Mp a multiple of 128 (the large-model shapes): TWO adjacent inducing points per thread, so that a lane stores
+// 16 bytes, and the row written with a nontemporal hint - the 8-byte-per-lane stores of the kernel above reach 3.3 TB/s
+// (the store path, not the exponentials, set its 0.73 ms per 10^6 x 256 values; tools/kuf_bench.hip: 0.62 ms with the
+// exponential removed, 0.45 ms with the store removed); this form writes at 4.5-4.8 TB/s: 0.43-0.46 ms.  A block covers
+// up to 256 columns; with TPR = columns / 2 threads per row its 256 threads take 256 / TPR point rows at a time, a row per
+// whole waves (TPR >= 64), so the point's x stays a scalar load.
+template <int DIN>
+__global__ __launch_bounds__(256) void rbf_kuf2_kernel(const double* __restrict__ Xin, long P, long x_row0,
+                                                       const double* __restrict__ Z, const double* __restrict__ var,
+                                                       const double* __restrict__ ls, int M, int Mp, double* __restrict__ Kt,
+                                                       int pts_per_block, int kind, double* __restrict__ Et, int tpr) {
+  const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x / tpr);     // which of the block's concurrent rows
+  const int nsub = 256 / tpr;
+  const int m = blockIdx.y * 256 + 2 * ((int)threadIdx.x % tpr);
+  double zs[2][DIN], il[DIN];
+#pragma unroll
+  for (int j = 0; j < DIN; ++j) {
+    il[j] = 1.0 / ls[j];
+    zs[0][j] = (m < M) ? Z[(long)m * DIN + j] * il[j] : 0.0;
+    zs[1][j] = (m + 1 < M) ? Z[(long)(m + 1) * DIN + j] * il[j] : 0.0;
+  }
+  const double v0 = var[0];
+  const long p0 = (long)blockIdx.x * pts_per_block;
+  const long p1 = min(P, p0 + pts_per_block);
+  for (long p = p0 + sub; p < p1; p += nsub) {
+    const double* __restrict__ x = Xin + (x_row0 + p) * DIN;       // wave-uniform address: scalar loads
+    double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < DIN; ++j) {
+      const double xs = x[j] * il[j];
+      const double d0 = xs - zs[0][j], d1 = xs - zs[1][j];
+      r0 += d0 * d0; r1 += d1 * d1;
+    }
+    d2_t k, e;
+    if (kind == 0) {
+      k[0] = v0 * exp_nonpos(-0.5 * r0); k[1] = v0 * exp_nonpos(-0.5 * r1);
+    } else {
+      double k0, e0, k1, e1;
+      stationary_k(kind, v0, r0, k0, e0);
+      stationary_k(kind, v0, r1, k1, e1);
+      k[0] = k0; k[1] = k1; e[0] = e0; e[1] = e1;
+    }
+    if (m >= M) k[0] = 0.0;
+    if (m + 1 >= M) k[1] = 0.0;
+    __builtin_nontemporal_store(k, reinterpret_cast<d2_t*>(Kt + p * Mp + m));
+    if (kind != 0 && Et) {
+      if (m >= M) e[0] = 0.0;
+      if (m + 1 >= M) e[1] = 0.0;
+      __builtin_nontemporal_store(e, reinterpret_cast<d2_t*>(Et + p * Mp + m));
+    }
+  }
+}
+
+template <int DIN>
+static void launch_kuf2(hipStream_t st, int kind, const double* Xin, long P, long x_row0, const double* Z, const double* var,
+                        const double* ls, int M, int Mp, double* Kt, double* Et) {
+  const int cols = Mp % 256 == 0 ? 256 : 128, tpr = cols / 2;
+  int ppb = 64;
+  while (ppb > 256 / tpr && (P + ppb - 1) / ppb < 2048) ppb >>= 1;      // enough blocks to fill the chip
+  dim3 grid((unsigned)((P + ppb - 1) / ppb), (unsigned)(Mp / cols));
+  // (a block's column base is blockIdx.y * 256 in the kernel: with 128-column blocks only Mp = 128 takes this path)
+  hipLaunchKernelGGL(rbf_kuf2_kernel<DIN>, grid, dim3(256), 0, st, Xin, P, x_row0, Z, var, ls, M, Mp, Kt, ppb, kind, Et, tpr);
+}
+
 hipError_t rbf_kuf(hipStream_t st, int kind, const double* Xin, long P, long x_row0, const double* Z, const double* var,
                    const double* ls, int M, int Mp, int Din, double* Kt, double* Et) {
   if (P == 0) return hipSuccess;
+  if ((Mp % 256 == 0 || Mp == 128) && (reinterpret_cast<uintptr_t>(Kt) & 15u) == 0 && (reinterpret_cast<uintptr_t>(Et) & 15u) == 0) {
+    bool done = true;
+    switch (Din) {
+      case 1: launch_kuf2<1>(st, kind, Xin, P, x_row0, Z, var, ls, M, Mp, Kt, Et); break;
+      case 2: launch_kuf2<2>(st, kind, Xin, P, x_row0, Z, var, ls, M, Mp, Kt, Et); break;
+      case 3: launch_kuf2<3>(st, kind, Xin, P, x_row0, Z, var, ls, M, Mp, Kt, Et); break;
+      case 4: launch_kuf2<4>(st, kind, Xin, P, x_row0, Z, var, ls, M, Mp, Kt, Et); break;
+      case 8: launch_kuf2<8>(st, kind, Xin, P, x_row0, Z, var, ls, M, Mp, Kt, Et); break;
+      case 16: launch_kuf2<16>(st, kind, Xin, P, x_row0, Z, var, ls, M, Mp, Kt, Et); break;
+      default: done = false; break;
+    }
+    if (done) LAUNCH_CHECK();
+  }
   int ppb = 64;
   while (ppb > 1 && (P + ppb - 1) / ppb < 2048) ppb >>= 1;           // enough blocks to fill the chip
   dim3 grid((unsigned)((P + ppb - 1) / ppb), (unsigned)((Mp + 255) / 256));
