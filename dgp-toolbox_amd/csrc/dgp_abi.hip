@@ -605,7 +605,27 @@ constexpr int kNcclFloat64 = 8, kNcclSum = 0;     // ncclDataType_t / ncclRedOp_
 
 int nccl_load(dgp_ctx* ctx) {
   if (g_nccl.lib) return DGP_OK;
-  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);        // the process's copy when one is loaded already
+  // RCCL must sit on the SAME HIP runtime this library is bound to: a process that also holds torch may contain two ROCm
+  // stacks (torch ships its own libamdhip64 / librccl with the system's sonames; which libamdhip64 this library got
+  // depends on what was loaded first), and a communicator created by the other stack's RCCL fails with "unhandled cuda
+  // error" on this library's streams and buffers.  So: the librccl next to the libamdhip64 that hipGetDeviceCount resolves to
+  // (when torch was loaded first that is torch's copy, already in the process: same handle), else the soname.
+  void* h = nullptr;
+  {
+    Dl_info di;
+    if (dladdr(reinterpret_cast<void*>(static_cast<hipError_t (*)(int*)>(&hipGetDeviceCount)), &di) && di.dli_fname) {
+      std::string dir(di.dli_fname);
+      const size_t slash = dir.rfind('/');
+      if (slash != std::string::npos) {
+        dir.resize(slash + 1);
+        for (const char* nm : {"librccl.so.1", "librccl.so"}) {
+          h = dlopen((dir + nm).c_str(), RTLD_NOW | RTLD_GLOBAL);
+          if (h) break;
+        }
+      }
+    }
+  }
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) return fail(ctx, DGP_ERR_INVALID, "dgp_comm: librccl.so not found");
   NcclApi a;

@@ -257,47 +257,68 @@ __global__ __launch_bounds__(256) void finalize_layer_kernel(
   }
 }
 
-// The same stage with one thread per POINT looping over the outputs: |c|^2 is read once per point and the [P, D]
-// arrays (mean0 in; mean, var, F out) as one contiguous row per thread instead of with stride D.  Used for large P
-// (0.80 -> 0.60 ms at P = 1e6, D = 8); at small P the (d, p) version above has D times the threads and wins.
-__global__ __launch_bounds__(256) void finalize_layer_rows_kernel(
+// The same stage for large P, every HBM access coalesced: a block takes 256 consecutive points.  Phase 1: thread = point -
+// sums the row-norm planes (reads with p fastest) and leaves |c|^2 and up to 8 of the |t_d|^2 in LDS.  Phase 2: thread =
+// (point, output) in memory order of the [P, D] arrays - mean0 / mean / var / F are read and written as contiguous rows
+// (the per-point kernel above wrote them 8 bytes per lane at a stride of D doubles: 0.45 ms at P = 1e6, D = 8; the planes
+// are summed in the same order, so the results are bit-identical).
+__global__ __launch_bounds__(256) void finalize_layer_tiled_kernel(
     const double* __restrict__ cnp, const double* __restrict__ tnp, int nplane, long pstride,
     const double* __restrict__ mean0,
     const double* __restrict__ Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
     const double* __restrict__ kvar, int mean_kind, const double* __restrict__ meanW, const double* __restrict__ meanb,
     ZSource zsrc, long n_chunk0, double* __restrict__ mean, double* __restrict__ var, double* __restrict__ F,
     int kernel_kind, const double* __restrict__ white) {
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  double cn = 0.0;
-  for (int q = 0; q < nplane; ++q) cn += cnp[(long)q * pstride + p];
-  const double* x = Xin + (x_row0 + p) * Din;
-  double kd = kvar[0];
-  if (kernel_kind == 3) {
-    const double f = x[Din - 1];
-    kd = kvar[0] * (kvar[2] + kvar[4] * f * f) + kvar[5];
+  __shared__ double s_cn[256];
+  __shared__ double s_tn[8][257];
+  const long pb = (long)blockIdx.x * 256;
+  const int t = threadIdx.x;
+  const long pt = pb + t;
+  {
+    double cn = 0.0;
+    if (pt < P)
+      for (int q = 0; q < nplane; ++q) cn += cnp[(long)q * pstride + pt];
+    s_cn[t] = cn;
   }
-  if (white) kd += white[0];
-  const int s1 = dedup ? 0 : (int)(p / Nc);
-  const long i1 = dedup ? p : p % Nc;
-  for (int d = 0; d < D; ++d) {
-    double tn = 0.0;
-    for (int q = 0; q < nplane; ++q) tn += tnp[((long)d * nplane + q) * pstride + p];
-    double mf = 0.0;
-    if (mean_kind == 1) mf = x[d];
-    else if (mean_kind == 2) {
-      for (int j = 0; j < Din; ++j) mf += x[j] * meanW[(long)j * D + d];
-      mf += meanb[d];
-    }
-    const double mv = mean0[p * D + d] + mf, vv = kd - cn + tn;
-    mean[p * D + d] = mv;
-    var[p * D + d] = vv;
-    if (F) {
-      const double sd = sqrt(vv + kJitter);
-      if (dedup) {
-        for (int s = 0; s < S; ++s) F[((long)s * Nc + p) * D + d] = mv + draw_z(zsrc, s, n_chunk0 + p, d, D) * sd;
-      } else {
-        F[p * D + d] = mv + draw_z(zsrc, s1, n_chunk0 + i1, d, D) * sd;
+  const int npts = (int)min((long)256, P - pb);
+  for (int d0 = 0; d0 < D; d0 += 8) {
+    const int dn = min(8, D - d0);
+    __syncthreads();
+    if (pt < P)
+      for (int dd = 0; dd < dn; ++dd) {
+        double tn = 0.0;
+        for (int q = 0; q < nplane; ++q) tn += tnp[((long)(d0 + dd) * nplane + q) * pstride + pt];
+        s_tn[dd][t] = tn;
+      }
+    __syncthreads();
+    for (int o = t; o < npts * dn; o += 256) {
+      const int pl = o / dn, dd = o - pl * dn, d = d0 + dd;
+      const long p = pb + pl;
+      const double* x = Xin + (x_row0 + p) * Din;
+      double mf = 0.0;
+      if (mean_kind == 1) mf = x[d];
+      else if (mean_kind == 2) {
+        for (int j = 0; j < Din; ++j) mf += x[j] * meanW[(long)j * D + d];
+        mf += meanb[d];
+      }
+      double kd = kvar[0];
+      if (kernel_kind == 3) {
+        const double f = x[Din - 1];
+        kd = kvar[0] * (kvar[2] + kvar[4] * f * f) + kvar[5];
+      }
+      if (white) kd += white[0];
+      const double mv = mean0[p * D + d] + mf, vv = kd - s_cn[pl] + s_tn[dd][pl];
+      mean[p * D + d] = mv;
+      var[p * D + d] = vv;
+      if (F) {
+        const double sd = sqrt(vv + kJitter);
+        if (dedup) {
+          for (int s = 0; s < S; ++s) F[((long)s * Nc + p) * D + d] = mv + draw_z(zsrc, s, n_chunk0 + p, d, D) * sd;
+        } else {
+          const int s1 = (int)(p / Nc);
+          const long i1 = p % Nc;
+          F[p * D + d] = mv + draw_z(zsrc, s1, n_chunk0 + i1, d, D) * sd;
+        }
       }
     }
   }
@@ -326,8 +347,8 @@ hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, 
   // above would walk the S samples of a point in one thread (0.75 ms for one candidate) - they leave F to expand_f_kernel
   const bool wide_s = dedup && F != nullptr && S > 16;
   double* Fk = wide_s ? nullptr : F;
-  if (P >= 400000 && D > 1)
-    hipLaunchKernelGGL(finalize_layer_rows_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, cnp, tnp, nplane, pstride,
+  if (P >= 32768 && D > 1)
+    hipLaunchKernelGGL(finalize_layer_tiled_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, cnp, tnp, nplane, pstride,
                        mean0, Xin, x_row0, P, Nc, S, dedup, Din, D, kvar, mean_kind, meanW, meanb, zsrc, n_chunk0, mean, var, Fk,
                        kernel_kind, white);
   else
@@ -596,38 +617,55 @@ hipError_t make_x1(hipStream_t st, const double* Xin, long x_row0, long P, int D
   LAUNCH_CHECK();
 }
 
+// x-gradient of the stationary kernels and the sum over the points of x_j^2 rowsum(g) (the lengthscale gradient's second
+// part).  One thread per (point, input j) in memory order of the [P, Din] arrays: xbar, mbar (identity mean) and the rows of
+// R1 / X1 are touched as contiguous pieces (the first version gave every j its own blocks, each striding over 72-byte rows:
+// 0.2-0.3 ms per 10^6 points against 0.06 ms of traffic).  The per-j sums meet in LDS, one global atomic per block and j.
 __global__ __launch_bounds__(256) void xbar_finish_kernel(const double* __restrict__ R1, const double* __restrict__ X1, long P,
                                                           const double* __restrict__ ls, int Din, int D, int mean_kind,
                                                           const double* __restrict__ meanW, const double* __restrict__ mbar,
                                                           int want_xbar, double* __restrict__ xbar,
                                                           double* __restrict__ acc_x2rs) {
-  __shared__ double sh[4];
+  __shared__ double s_x2[64];
   const int w = Din + 1;
-  // one block handles all points for a fixed j (grid.y = Din): coalescing is secondary here (72 B per point)
-  const int j = blockIdx.y;
-  const double l = ls[j], il2 = 1.0 / (l * l);
+  if (threadIdx.x < 64) s_x2[threadIdx.x] = 0.0;
+  __syncthreads();
+  const long total = P * Din;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const bool fixed_j = stride % Din == 0;        // a thread then keeps its j: its sum stays in a register until the end
   double x2 = 0.0;
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+  int j_last = 0;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const long p = idx / Din;
+    const int j = (int)(idx - p * Din);
+    j_last = j;
+    const double l = ls[j], il2 = 1.0 / (l * l);
     const double rs = R1[p * w + Din], x = X1[p * w + j];
-    x2 += x * x * rs;
+    if (acc_x2rs) {
+      if (fixed_j) x2 += x * x * rs;
+      else atomicAdd(&s_x2[j], x * x * rs);
+    }
     if (want_xbar) {
       double a = (R1[p * w + j] - x * rs) * il2;
       const double* mb = mbar + p * D;
       if (mean_kind == 1) a += mb[j];
       else if (mean_kind == 2)
         for (int d = 0; d < D; ++d) a += meanW[(long)j * D + d] * mb[d];
-      xbar[p * Din + j] = a;
+      xbar[idx] = a;
     }
   }
-  if (acc_x2rs) block_atomic_add(x2, acc_x2rs + j, sh);
+  if (acc_x2rs && fixed_j && x2 != 0.0) atomicAdd(&s_x2[j_last], x2);
+  __syncthreads();
+  if (acc_x2rs && (int)threadIdx.x < Din) unsafeAtomicAdd(acc_x2rs + threadIdx.x, s_x2[threadIdx.x]);
 }
 hipError_t xbar_finish(hipStream_t st, const double* R1, const double* X1, long P, const double* ls, int Din, int D,
                        int mean_kind, const double* meanW, const double* mbar, int want_xbar, double* xbar,
                        double* acc_x2rs) {
   if (P == 0) return hipSuccess;
-  long blocks = (P + 255) / 256;
-  if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(xbar_finish_kernel, dim3((unsigned)blocks, Din), dim3(256), 0, st, R1, X1, P, ls, Din, D, mean_kind, meanW,
+  if (Din > 64) return hipErrorInvalidValue;
+  long blocks = (P * Din + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(xbar_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, st, R1, X1, P, ls, Din, D, mean_kind, meanW,
                      mbar, want_xbar, xbar, acc_x2rs);
   LAUNCH_CHECK();
 }

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -53,6 +54,29 @@ _dpp = C.POINTER(_dp)
 _lib = None
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process.  torch's wheels ship their own libamdhip64.so / libhsa-runtime64.so / librccl.so with the
+    SAME sonames as the system ROCm's.  The dynamic loader resolves this library's `libamdhip64.so.7` to whichever copy is
+    already in the process - but torch asks for its copy by file name, so `import torch` AFTER this library brings a second
+    runtime in, and a process that then uses torch.cuda runs two HSA runtimes on one GPU (seen: RCCL of one stack handed
+    the other's streams -> "unhandled cuda error"; `double free or corruption` at exit).  When torch is installed and not
+    yet imported, its libamdhip64.so is therefore mapped first (no import of torch, no device touched), so that this
+    library, a later `import torch` and RCCL all share it.  DGP_HIP_RUNTIME=system skips this (a process that never
+    imports torch)."""
+    if os.environ.get("DGP_HIP_RUNTIME", "shared") == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:       # noqa: BLE001   (no torch, or an unusual layout: the system runtime is the only one)
+        pass
+
+
 def load():
     """Load the shared library (no device is touched)."""
     global _lib
@@ -62,6 +86,7 @@ def load():
         raise NativeUnavailable(
             f"{LIB_PATH} not found: build it with `make -C dgp-toolbox_amd/csrc` (hipcc, gfx950). "
             "There is no CPU fallback for the DGP hot path.")
+    _one_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
     sig = {
@@ -334,26 +359,14 @@ class Context:
 
     # ---- multi-GPU: library-owned RCCL communicator ---------------------------------------------
     @staticmethod
-    def _rccl_first_from_torch():
-        """The library binds RCCL with dlopen("librccl.so.1"): the process's copy when one is loaded already.  torch ships
-        its own librccl; if the library loaded the system copy FIRST and torch came later, the process would hold two RCCL
-        runtimes (seen as `double free or corruption` at exit).  So torch, when installed, is imported before the first
-        dlopen."""
-        try:
-            import torch  # noqa: F401
-        except Exception:      # noqa: BLE001   (no torch: the system librccl is the only copy)
-            pass
-
-    @staticmethod
     def comm_available():
-        """True when librccl.so loads with every entry point the library binds (no communicator is created)."""
-        Context._rccl_first_from_torch()
+        """True when librccl.so loads with every entry point the library binds (no communicator is created).  The library
+        takes the librccl that sits next to the HIP runtime it is bound to (csrc/dgp_abi.hip: nccl_load)."""
         return load().dgp_comm_available() == DGP_OK
 
     @staticmethod
     def comm_unique_id():
         """128 bytes (ncclUniqueId) from rank 0, to be broadcast to the other ranks by the host."""
-        Context._rccl_first_from_torch()
         lib = load()
         buf = C.create_string_buffer(128)
         rc = lib.dgp_comm_unique_id(C.cast(buf, C.c_void_p))
@@ -362,8 +375,6 @@ class Context:
         return bytes(buf.raw)
 
     def comm_init(self, rank, world, unique_id=None):
-        if unique_id is not None:
-            self._rccl_first_from_torch()
         buf = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
         self._chk(self._lib.dgp_comm_init(self._h, int(rank), int(world), C.cast(buf, C.c_void_p) if buf is not None else None))
         self.comm_world = int(world)

@@ -221,13 +221,15 @@ def test_grad_step_equals_partial_reduce_finish():
     e3 = ctx.grad_step(int(g["S"]), 0, zs, want_elbo=True)
     assert abs(e3 - e0) <= 1e-13 * abs(e0)
     np.testing.assert_allclose(ctx.grad_get(), g0, rtol=1e-12, atol=1e-12 * np.abs(g0).max())
-    import torch
+    # the three-stage form with the library's communicator between the stages: dgp_grad_partial, dgp_comm_allreduce on the
+    # partial-sum buffer (one rank: the identity), dgp_grad_finish
     assert Context.comm_available()
-    t = torch.arange(1000, dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()              # `t` is filled on torch's stream, the all-reduce runs on the context's own
-    ctx.comm_allreduce(t.data_ptr(), t.numel())
-    ctx.sync()
-    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
+    ctx.grad_partial(int(g["S"]), 0, zs)
+    ptr, n = ctx.acc_info()
+    ctx.comm_allreduce(ptr, n)
+    e4 = ctx.grad_finish(want_elbo=True)
+    assert abs(e4 - e0) <= 1e-13 * abs(e0)
+    np.testing.assert_allclose(ctx.grad_get(), g0, rtol=1e-12, atol=1e-12 * np.abs(g0).max())
     ctx.comm_destroy()
     with pytest.raises(ValueError):
         ctx.grad_step(int(g["S"]), 0, zs[:-1])                 # wrong number of injected arrays
