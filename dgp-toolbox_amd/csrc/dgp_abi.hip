@@ -46,6 +46,22 @@ int dgp_create(int device, void* hip_stream, dgp_ctx** out) {
       ok = hipEventCreateWithFlags(&ctx->ev_prep[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&ctx->ev_layer[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&ctx->ev_red[i], hipEventDisableTiming) == hipSuccess;
+    {
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (ok && hipStreamCreateWithPriority(&ctx->bst, hipStreamNonBlocking, least) == hipSuccess &&
+          hipEventCreateWithFlags(&ctx->ev_b[0], hipEventDisableTiming) == hipSuccess &&
+          hipEventCreateWithFlags(&ctx->ev_b[1], hipEventDisableTiming) == hipSuccess) {
+        const char* ob = getenv("DGP_OVERLAP_B");
+        ctx->overlap_b = ob && ob[0] == '1';
+        if (const char* r = getenv("DGP_OVERLAP_RESERVE")) ctx->overlap_reserve_wide = atoi(r);
+        if (const char* r = getenv("DGP_OVERLAP_RESERVE_NARROW")) ctx->overlap_reserve_narrow = atoi(r);
+        if (const char* r = getenv("DGP_OVERLAP_MIN_WORK")) ctx->overlap_min_work = atof(r);
+      } else {
+        ctx->overlap_b = false;
+        (void)hipGetLastError();
+      }
+    }
     // one flag for all of them: a partial failure leaves every side path off (dgp_destroy releases what exists)
     ctx->events_ok = ok;
     if (!ok) { ctx->use_side = false; (void)hipGetLastError(); }
@@ -67,6 +83,8 @@ void dgp_destroy(dgp_ctx* ctx) {
     if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); }
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
+  if (ctx->bst) { (void)hipStreamSynchronize(ctx->bst); (void)hipStreamDestroy(ctx->bst); }
+  for (auto& e : ctx->ev_b) if (e) (void)hipEventDestroy(e);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   (void)dgp_comm_destroy(ctx);
   drop_graph(ctx);

@@ -130,7 +130,13 @@ struct dgp_ctx {
   hipEvent_t ev_prep[kMaxEv] = {nullptr}, ev_layer[kMaxEv] = {nullptr}, ev_red[kMaxEv] = {nullptr};
   bool events_ok = false;   // every stream and event above exists (tested wherever the side path is taken)
   bool prep_wait[kMaxEv] = {false};
-  bool side_touched[kSide] = {false};   // side streams that got work in the current dgp_grad_step (joined at its end)
+  bool side_touched[kSide] = {false};
+  // the backward pass's HBM-bound part on a low-priority stream beside its matrix-core-bound reductions (backward_chunk)
+  hipStream_t bst = nullptr;
+  hipEvent_t ev_b[2] = {nullptr, nullptr};
+  bool overlap_b = false;     // measured slower (NOTES.md): the HBM-bound kernels need most of the chip's CUs for their bandwidth
+  int overlap_reserve_wide = 32, overlap_reserve_narrow = 96;   // CUs left to B by the Gram kernel: layers with D >= 4 / fewer outputs
+  double overlap_min_work = 2.0e7;                               // smallest layer (points x Mp) that is split   // side streams that got work in the current dgp_grad_step (joined at its end)
   // library-owned RCCL communicator (dgp_comm_init); the functions come from dlopen("librccl.so.1")
   // captured-graph training loop (dgp_adam_iterations): device-side iteration state, ELBO log, the instantiated graph
   long ws_key_N = -1, ws_key_Nc = 0, ws_key_limit = 0;   // last workspace request (ensure_ws)
@@ -245,7 +251,7 @@ int GX(dgp_ctx* ctx, int cat, GemmOp op, GemmArgs a, double flops = 0.0, double 
   ProfScope ps(ctx, cat, flops, bytes);
   // (the Gram kernel's scratch - one buffer per context, not stream-safe - is attached only by the callers that reduce
   //  over the points on the context's main stream: backward_chunk's G_d / Q' and the unit hooks)
-  a.cu_count = ctx->cu_count; a.reserve_cus = ctx->reserved_cus;
+  a.cu_count = ctx->cu_count; a.reserve_cus = std::max(a.reserve_cus, ctx->reserved_cus);
   HIPCHK(gemm_f64(ctx->st, op, a));
   return DGP_OK;
 }
@@ -729,6 +735,23 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       // algorithmic count: the D triangular products W_d t_d of SURVEY App. C (the dense S' form executes 2x that)
       RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 16));
     }
+    // ---- from here the layer's work splits into two independent parts that only read dC:
+    //   B (HBM-bound, no matrix-core time to speak of): g = dK .* k, the two skinny contractions of g, the x-gradient, the
+    //     fold into the layer below, du = Ct^T mbar - 6 GB + 3 x 2 GB of streaming per 10^6 points;
+    //   A (matrix-core bound): the reductions over the points G_d and Q'.
+    // With `overlap_b` they run side by side: B on the context's low-priority stream, A on the main stream with R CUs left
+    // free by its persistent one-workgroup-per-CU kernels (GemmArgs::reserve_cus; a workgroup of those fills its CU, so
+    // without the reservation B would only start when A ends).  The main stream rejoins B before it leaves the layer
+    // (the layer below needs mbar / vbar from B's fold; the layer's sums must be final for the after_layer hook).
+    hipStream_t main_st = ctx->st;
+    const bool ovl = ctx->overlap_b && ctx->bst != nullptr && o.params && y.d.kernel_kind != DGP_KERNEL_MF &&
+                     (double)Pl * Mp >= ctx->overlap_min_work;
+    if (ovl) {
+      HIPCHK(hipEventRecord(ctx->ev_b[0], main_st));
+      HIPCHK(hipStreamWaitEvent(ctx->bst, ctx->ev_b[0], 0));
+      ctx->st = ctx->bst;
+    }
+    struct BackToMain { dgp_ctx* c; hipStream_t m; ~BackToMain() { c->st = m; } } back_to_main{ctx, main_st};
     {
       // g = dK .* e (e = -2 dk/dr2; = k for the squared exponential).  dK itself has one more reader, Q = dK^T C =
       // Linv^T (Cbar^T C): that reduction takes Cbar instead (finish_layer applies Linv^T to the summed 256 x 256 result), so
@@ -736,26 +759,9 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       GemmArgs a = args_g(Pm, Mp, ctx->Cbar, y.Linv, ctx->Kbar, y.d.kernel_kind != DGP_KERNEL_MF ? (y.Et ? y.Et : y.Kt) : nullptr, ctx->Gt);
       RET(GX(ctx, 0, GEMM_NN, a, tri1, (double)Pl * Mp * 32));
     }
-    // reductions over the chunk's points (accumulate into the all-reduce buffer)
     if (o.params) {
-    {  // G_d = sum_p vbar_pd c_p c_p^T   (lower triangle; dW_d = 2 G_d W_d after the all-reduce)
-      GemmArgs a = mk(Mp, Mp, Pl, y.Ct, Mp, y.Ct, Mp, acc + y.acc_G, Mp, 1.0, 1);
-      a.batch = D; a.sC = MM; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp) * D, Pl, (long)Mp * 8);
-      a.ascale = y.vbar; a.as_ld = D; a.ascale_mode = 2;
-      a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = ctx->gram_ws ? gemm_gram_ws_bytes(ctx->cu_count) : 0;     // (Mp = 256: gemm_gram.h)
-      RET(GX(ctx, 0, GEMM_TN, a, tri1 * D, (double)Pl * Mp * 8));
-    }
-    {
-      // Q' = Cbar^T C (stationary kernels; Q = Linv^T Q' in finish_layer) or Q = dK^T C (composite kernel: dK is stored)
-      GemmArgs a = mk(Mp, Mp, Pl, y.d.kernel_kind != DGP_KERNEL_MF ? ctx->Cbar : ctx->Kbar, Mp, y.Ct, Mp, acc + y.acc_Q, Mp, 1.0, 1);
-      a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp), Pl, (long)Mp * 16);
-      a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = ctx->gram_ws ? gemm_gram_ws_bytes(ctx->cu_count) : 0;     // (Mp = 256: gemm_gram.h, two sources)
-      RET(GX(ctx, 0, GEMM_TN, a, tri1, (double)Pl * Mp * 16));
-    }
-    {
       GemmArgs a = args_du(ctx, Pl, Mp, D, y.Ct, y.mbar, acc + y.acc_du);
       RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
-    }
     }
     if (y.d.kernel_kind == DGP_KERNEL_MF) {   // non-stationary kernel: direct pair reductions of dK (mfkern.hip)
       ProfScope ps(ctx, 1, 0, (double)Pl * Mp * 16);
@@ -790,6 +796,31 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
                               zsrc_of(ctx, l - 1, use_zs, seed, o.n_goff, o.Ntot), n0, w.mbar, w.vbar,
                               o.params ? acc + w.acc_dvar : nullptr));
     }
+    if (ovl) {
+      HIPCHK(hipEventRecord(ctx->ev_b[1], ctx->bst));
+      ctx->st = main_st;
+    }
+    // reductions over the chunk's points (accumulate into the all-reduce buffer)
+    if (o.params) {
+    const int reserve = ovl ? (D >= 4 ? ctx->overlap_reserve_wide : ctx->overlap_reserve_narrow) : 0;
+    {  // G_d = sum_p vbar_pd c_p c_p^T   (lower triangle; dW_d = 2 G_d W_d after the all-reduce)
+      GemmArgs a = mk(Mp, Mp, Pl, y.Ct, Mp, y.Ct, Mp, acc + y.acc_G, Mp, 1.0, 1);
+      a.batch = D; a.sC = MM; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp) * D, Pl, (long)Mp * 8);
+      a.ascale = y.vbar; a.as_ld = D; a.ascale_mode = 2;
+      a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = ctx->gram_ws ? gemm_gram_ws_bytes(ctx->cu_count) : 0;     // (Mp = 256: gemm_gram.h)
+      a.reserve_cus = reserve;
+      RET(GX(ctx, 0, GEMM_TN, a, tri1 * D, (double)Pl * Mp * 8));
+    }
+    {
+      // Q' = Cbar^T C (stationary kernels; Q = Linv^T Q' in finish_layer) or Q = dK^T C (composite kernel: dK is stored)
+      GemmArgs a = mk(Mp, Mp, Pl, y.d.kernel_kind != DGP_KERNEL_MF ? ctx->Cbar : ctx->Kbar, Mp, y.Ct, Mp, acc + y.acc_Q, Mp, 1.0, 1);
+      a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp), Pl, (long)Mp * 16);
+      a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = ctx->gram_ws ? gemm_gram_ws_bytes(ctx->cu_count) : 0;     // (Mp = 256: gemm_gram.h, two sources)
+      a.reserve_cus = reserve;
+      RET(GX(ctx, 0, GEMM_TN, a, tri1, (double)Pl * Mp * 16));
+    }
+    }
+    if (ovl) HIPCHK(hipStreamWaitEvent(main_st, ctx->ev_b[1], 0));
     if (o.after_layer) RET(o.after_layer(ctx, l));
   }
   return DGP_OK;

@@ -62,10 +62,29 @@ struct GramArgs {
 };
 constexpr long GR_SLOT_DOUBLES = 136L * 256;
 constexpr long GR_SLOT_BYTES = GR_SLOT_DOUBLES * 8;
-// Work split: the D * KT k-tiles (KT = P / 16), d-major, are cut into gridDim.x equal contiguous ranges; workgroup b owns
-// [F b / G, F (b + 1) / G): at most TWO d (D <= G), i.e. at most two segments, each with its own partial triangle
-// (slot 2 b + segment).  Every workgroup therefore flushes once or twice per launch, whatever D.
-__host__ __device__ inline long gram_cut(long F, long b, long G) { return (F * b) / G; }
+// Work split, XCD-grouped for ANY grid size G >= 8 D.  Workgroups are dealt round-robin to the 8 XCDs (b % 8, observed
+// placement; speed only): XCD x holds n_x = ceil((G - x) / 8) of them and gets a share n_x / G of the points (k-tiles
+// [KT c_x / G, KT c_{x+1} / G), c_x = workgroups on the XCDs before x).  Inside an XCD its KTx * D k-tiles, d-major, are cut
+// into n_x equal contiguous ranges: workgroup idx = b / 8 owns [Fx idx / n_x, Fx (idx + 1) / n_x) - at most TWO d (D <= n_x),
+// i.e. at most two segments, each with its own partial triangle (slot 2 b + segment).  The D workgroups that stream the
+// same points therefore sit on ONE XCD and walk them at the same time (idx, idx + n_x / D, ...: one HBM fetch, D - 1 L2
+// hits) whatever G is: the first version cut the global d-major list into G ranges, which kept those readers on one XCD
+// only when G was a multiple of 8 D (with 248 of 256 workgroups - eight CUs left to a collective - the launch fetched 62
+// instead of 13 GB per three iterations).
+struct GramRange { long kt0, ktn; long f_lo, f_hi; };      // the XCD's k-tiles [kt0, kt0 + ktn); the workgroup's local f range
+__host__ __device__ inline GramRange gram_range(long KT, int D, unsigned b, unsigned G) {
+  const unsigned x = b % 8u, idx = b / 8u;
+  const unsigned q = G / 8u, r = G % 8u;                  // XCD y holds q + (y < r) workgroups
+  const unsigned n_x = q + (x < r ? 1u : 0u);
+  const unsigned c_x = x * q + (x < r ? x : r);
+  GramRange g;
+  g.kt0 = (KT * (long)c_x) / (long)G;
+  g.ktn = (KT * (long)(c_x + n_x)) / (long)G - g.kt0;
+  const long Fx = g.ktn * D;
+  g.f_lo = (Fx * (long)idx) / (long)n_x;
+  g.f_hi = (Fx * (long)(idx + 1)) / (long)n_x;
+  return g;
+}
 
 
 // A wave's 17 blocks, in one or two GROUPS: group q has row blocks rows[q][0..nr[q]) and column blocks
@@ -150,8 +169,9 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
   // (bit 0 only), + (m & 1) * 8: ONE per-lane address, the row block is a compile-time offset of 128 r bytes
   unsigned bA = (unsigned)((2 * lk) * 2048 + (((li >> 1) ^ sw) << 4) + (li & 1) * 8);
 
-  const long KT = g.P / 16, F = KT * g.D;
-  const long f_lo = gram_cut(F, blockIdx.x, gridDim.x), f_hi = gram_cut(F, blockIdx.x + 1, gridDim.x);
+  const long KT = g.P / 16;
+  const GramRange gr = gram_range(KT, g.D, blockIdx.x, gridDim.x);
+  const long f_lo = gr.f_lo, f_hi = gr.f_hi;
   long kt_lo = 0;             // current segment: k-tiles [kt_lo, kt_lo + nkt) of output d
   int nkt = 0;
 
@@ -221,9 +241,10 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
 
   int seg = 0;
   for (long f = f_lo; f < f_hi; f += nkt, ++seg) {
-    const int d = (int)(f / KT);
-    kt_lo = f - (long)d * KT;
-    nkt = (int)((KT - kt_lo) < (f_hi - f) ? (KT - kt_lo) : (f_hi - f));
+    const int d = (int)(f / gr.ktn);
+    const long koff = f - (long)d * gr.ktn;             // position inside the XCD's share of the points
+    kt_lo = gr.kt0 + koff;
+    nkt = (int)((gr.ktn - koff) < (f_hi - f) ? (gr.ktn - koff) : (f_hi - f));
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll

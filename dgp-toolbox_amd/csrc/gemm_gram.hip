@@ -5,33 +5,37 @@
 
 namespace dgp {
 
-// G[d] += sum of the partial triangles of d, in a fixed order.  One workgroup of 256 threads per (block, d): thread =
-// lane * 4 + e.  The workgroups whose ranges meet d's k-tiles [lo, hi) are consecutive; only the first of them can have
-// started in d - 1 (its partial of d is then its SECOND segment).
+// G[d] += sum of the partial triangles of d, in a fixed order (XCD by XCD, inside an XCD by workgroup index).  One
+// workgroup of 256 threads per (block, d): thread = lane * 4 + e.  Inside an XCD the workgroups whose ranges meet d's local
+// k-tiles [d KTx, (d + 1) KTx) are consecutive; only the first of them can have started in d - 1 (its partial of d is then
+// its SECOND segment).
 __global__ __launch_bounds__(256) void gram_reduce_kernel(GramArgs g, int grid) {
   const int id = blockIdx.x, d = blockIdx.y, t = threadIdx.x;
-  const long KT = g.P / 16, F = KT * g.D;
-  const long lo = (long)d * KT, hi = lo + KT;
-  long b0 = (lo * grid) / F;
-  while (b0 > 0 && gram_cut(F, b0, grid) > lo) --b0;
-  while (gram_cut(F, b0 + 1, grid) <= lo) ++b0;                 // first workgroup whose range ends after lo
-  long b1 = (hi * grid) / F;
-  if (b1 > grid) b1 = grid;
-  while (b1 < grid && gram_cut(F, b1, grid) < hi) ++b1;
-  while (b1 > b0 + 1 && gram_cut(F, b1 - 1, grid) >= hi) --b1;   // [b0, b1): ranges that start before hi
+  const long KT = g.P / 16;
   const double* __restrict__ w = g.ws + (long)id * 256 + t;
-  const int seg0 = d - (int)(gram_cut(F, b0, grid) / KT);
-  double sum = w[(b0 * 2 + seg0) * GR_SLOT_DOUBLES];
-  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  long b = b0 + 1;
-  for (; b + 8 <= b1; b += 8) {                                  // (eight independent loads in flight; fixed association)
-    double v[8];
-#pragma unroll
-    for (int x = 0; x < 8; ++x) v[x] = w[(b + x) * 2 * GR_SLOT_DOUBLES];
-    sum += v[0] + v[4]; s1 += v[1] + v[5]; s2 += v[2] + v[6]; s3 += v[3] + v[7];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (unsigned x = 0; x < 8u && x < (unsigned)grid; ++x) {
+    const unsigned n_x = (unsigned)grid / 8u + (x < (unsigned)grid % 8u ? 1u : 0u);
+    const GramRange r0 = gram_range(KT, g.D, x, (unsigned)grid);       // (idx 0: the XCD's k-tile share)
+    const long Fx = r0.ktn * g.D, lo = (long)d * r0.ktn, hi = lo + r0.ktn;
+    if (r0.ktn <= 0) continue;
+    // first workgroup whose range ends after lo, first whose range starts at or after hi
+    long i0 = (lo * n_x) / Fx;
+    while (i0 > 0 && (Fx * i0) / n_x > lo) --i0;
+    while ((Fx * (i0 + 1)) / n_x <= lo) ++i0;
+    long i1 = (hi * n_x) / Fx;
+    if (i1 > (long)n_x) i1 = n_x;
+    while (i1 < (long)n_x && (Fx * i1) / n_x < hi) ++i1;
+    while (i1 > i0 + 1 && (Fx * (i1 - 1)) / n_x >= hi) --i1;
+    for (long i = i0; i < i1; ++i) {
+      const long f_lo = (Fx * i) / n_x, f_hi = (Fx * (i + 1)) / n_x;
+      if (f_hi <= f_lo) continue;                                       // (an empty range stores nothing)
+      const int seg = d - (int)(f_lo / r0.ktn);                         // 0: the range starts in d; 1: it started in d - 1
+      const double v = w[(((long)x + 8 * i) * 2 + seg) * GR_SLOT_DOUBLES];
+      switch ((i - i0) & 3) { case 0: s0 += v; break; case 1: s1 += v; break; case 2: s2 += v; break; default: s3 += v; break; }
+    }
   }
-  for (; b < b1; ++b) sum += w[b * 2 * GR_SLOT_DOUBLES];
-  sum = (sum + s1) + (s2 + s3);
+  const double sum = (s0 + s1) + (s2 + s3);
   int r = 0;
   while ((r + 1) * (r + 2) / 2 <= id) ++r;
   const int c = id - r * (r + 1) / 2;
@@ -72,6 +76,8 @@ bool gemm_gram_ok(const GemmArgs& a) {
   if ((reinterpret_cast<uintptr_t>(a.A) & 15u) || (reinterpret_cast<uintptr_t>(a.B) & 15u) || (reinterpret_cast<uintptr_t>(a.C) & 7u)) return false;
   if (a.ascale && (reinterpret_cast<uintptr_t>(a.ascale) & 15u)) return false;
   if (a.gram_ws == nullptr || a.gram_ws_bytes < gemm_gram_ws_bytes(a.cu_count) || (reinterpret_cast<uintptr_t>(a.gram_ws) & 31u)) return false;
+  if (gemm_persistent_grid(a, gram_grid(a.cu_count)) < 8 * a.batch) return false;        // (every XCD's share is cut into >= D ranges)
+  if (a.K / 16 < 2L * gram_grid(a.cu_count)) return false;                                  // (every workgroup gets k-tiles)
   return true;
 }
 

@@ -55,25 +55,21 @@ _lib = None
 
 
 def _one_hip_runtime():
-    """One HIP runtime per process.  torch's wheels ship their own libamdhip64.so / libhsa-runtime64.so / librccl.so with the
+    """One ROCm stack per process.  torch's wheels ship their own libamdhip64.so / libhsa-runtime64.so / librccl.so with the
     SAME sonames as the system ROCm's.  The dynamic loader resolves this library's `libamdhip64.so.7` to whichever copy is
-    already in the process - but torch asks for its copy by file name, so `import torch` AFTER this library brings a second
-    runtime in, and a process that then uses torch.cuda runs two HSA runtimes on one GPU (seen: RCCL of one stack handed
-    the other's streams -> "unhandled cuda error"; `double free or corruption` at exit).  When torch is installed and not
-    yet imported, its libamdhip64.so is therefore mapped first (no import of torch, no device touched), so that this
-    library, a later `import torch` and RCCL all share it.  DGP_HIP_RUNTIME=system skips this (a process that never
-    imports torch)."""
+    already in the process - but torch asks for its copies by file name, so `import torch` AFTER this library brings a
+    second stack in.  Seen on the GPU box when that happened and the process also created an RCCL communicator or touched
+    torch.cuda: `ncclCommInitRank: unhandled cuda error` (RCCL of one stack handed the other's streams), `double free or
+    corruption` / `free(): invalid pointer` at exit.  Mapping only torch's libamdhip64 first was not enough (same aborts
+    at exit).  The order that every multi-rank launch has anyway - torch first, then this library, which then binds to
+    torch's stack, RCCL included (csrc/dgp_abi.hip: nccl_load) - is the one that runs clean, so when torch is installed
+    it is imported before the library is loaded.  DGP_HIP_RUNTIME=system skips this (a process that never imports
+    torch and wants the system ROCm)."""
     if os.environ.get("DGP_HIP_RUNTIME", "shared") == "system" or "torch" in sys.modules:
         return
     try:
-        import importlib.util
-        spec = importlib.util.find_spec("torch")
-        if spec is None or not spec.submodule_search_locations:
-            return
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(cand):
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-    except Exception:       # noqa: BLE001   (no torch, or an unusual layout: the system runtime is the only one)
+        import torch  # noqa: F401
+    except Exception:       # noqa: BLE001   (no torch: the system runtime is the only one)
         pass
 
 

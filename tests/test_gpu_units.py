@@ -132,6 +132,18 @@ def test_layer_products_on_the_wide_tile_kernel_modes_against_numpy():
     assert p.returncode == 0 and p.stdout.count("ok ") == len(specs), p.stdout
 
 
+@pytest.mark.parametrize("grid", ["256", "248", "232", "200", "72"])
+def test_gram_kernel_is_exact_for_any_grid(grid):
+    """The Gram kernel's work split keeps the D workgroups that stream the same points on one XCD for ANY workgroup count
+    (a collective or the side-stream kernels of the backward pass take CUs away from it): both forms against NumPy at
+    grids that are and are not multiples of 8 D.  The grid is read once per process: child process."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "gram_grid_check.py")], env=dict(os.environ, DGP_GRAM_GRID=grid),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.count("ok ") == 5, p.stdout
+
+
 @pytest.mark.parametrize("Mp", [128, 256, 272])
 def test_gemm_triangular_hints_are_exact(ctx, Mp):
     """TRI_* only skip structurally-zero work: results equal the dense product."""
