@@ -489,7 +489,8 @@ int dgp_grad_partial(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const
   HIPCHK(hipSetDevice(ctx->device));
   ctx->grad_ready = false;
   if (zs) RET(upload_zs(ctx, zs, S, ctx->N));
-  RET(prep(ctx, true));
+  SideJoin join{ctx, ctx->st, ctx->use_side && ctx->events_ok};
+  RET(prep(ctx, true, true));      // the upper layers' chains run under the first layer's forward pass
   HIPCHK(hipMemsetAsync(ctx->acc, 0, ctx->n_acc * 8, ctx->st));
   long Nc = 0;
   const long lo = ctx->batch_n ? ctx->batch_lo : 0, hi = ctx->batch_n ? ctx->batch_lo + ctx->batch_n : ctx->N;
@@ -507,6 +508,7 @@ int dgp_grad_partial(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const
     }
     RET(backward_chunk(ctx, n0, nc, S, seed, zs != nullptr, BwdOpts{ctx->X, ctx->N, ctx->n_goff, true, false}));
   }
+  RET(prep_flush(ctx));            // (no-op unless no chunk ran)
   return DGP_OK;
 }
 
@@ -763,25 +765,6 @@ int after_layer_hook(dgp_ctx* ctx, int l) {
   return r;
 }
 
-// joins every side stream back into the context's stream on EVERY exit of dgp_grad_step (also error returns: chains or
-// all-reduces already enqueued on the side streams must not race with the next call's memset of the partial-sum buffer)
-struct SideJoin {
-  dgp_ctx* ctx;
-  hipStream_t main;
-  bool on;
-  ~SideJoin() {
-    if (!on) return;
-    ctx->st = main;
-    ctx->sm = ctx->smset[0];
-    for (int i = 0; i < dgp_ctx::kSide; ++i) {
-      if (!ctx->side_touched[i]) continue;
-      (void)hipEventRecord(ctx->ev_join[i], ctx->side[i]);
-      (void)hipStreamWaitEvent(main, ctx->ev_join[i], 0);
-      ctx->side_touched[i] = false;
-    }
-    for (int l = 0; l < dgp_ctx::kMaxEv; ++l) ctx->prep_wait[l] = false;   // (all prep chains are joined now)
-  }
-};
 }  // namespace
 
 int dgp_grad_step(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs, double* elbo_out) {
@@ -814,6 +797,7 @@ int dgp_grad_step(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* z
       if (n0 + nc >= hi) { o.after_layer = after_layer_hook; hooked = true; }     // sums are final in the last chunk only
       RET(backward_chunk(ctx, n0, nc, S, seed, zs != nullptr, o));
     }
+    RET(prep_flush(ctx));   // (no-op unless no chunk ran: the upper layers' prep chains are still owed)
     if (!hooked) {          // no data points on this rank: the chains still have to run (KL part), after the all-reduces
       for (int l = nl - 1; l >= 0; --l) RET(after_layer_hook(ctx, l));
     }

@@ -131,6 +131,7 @@ struct dgp_ctx {
   bool events_ok = false;   // every stream and event above exists (tested wherever the side path is taken)
   bool prep_wait[kMaxEv] = {false};
   bool side_touched[kSide] = {false};
+  bool prep_deferred = false, prep_deferred_train = false;   // the upper layers' prep chains are still to be enqueued (prep_deferred_layers)
   // the backward pass's HBM-bound part on a low-priority stream beside its matrix-core-bound reductions (backward_chunk)
   hipStream_t bst = nullptr;
   hipEvent_t ev_b[2] = {nullptr, nullptr};
@@ -514,8 +515,69 @@ int upload_zs(dgp_ctx* ctx, const double* const* zs, int S, long Ntot) {
 inline const double* P(dgp_ctx* ctx, long off) { return ctx->params + off; }
 
 // ------------------------------------------------------------------------------- prep: small matrices + KL
-// `overlap`: the chains of the layers above the first run on the side streams WITHOUT a join; forward_chunk waits for
-// layer l's event right before it needs that layer's matrices (the first layer's forward pass covers the others' chains)
+// One layer's chain (Kuu, Cholesky + inverse, W, u, KL, the backward's transposes) on ctx->st with the scratch set ctx->sm.
+int prep_layer(dgp_ctx* ctx, size_t li, bool train) {
+  Layer& y = ctx->L[li];
+  const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
+  const long MM = (long)Mp * Mp;
+  HIPCHK(pack_q(ctx->st, P(ctx, y.off_qsqrt), P(ctx, y.off_qmu), M, Mp, D, y.Lq, y.qmu_p));
+  if (y.d.kernel_kind == DGP_KERNEL_MF)
+    HIPCHK(mf_kuu(ctx->st, P(ctx, y.off_Z), P(ctx, y.off_var), M, Mp, Din, y.Kuu));
+  else
+    HIPCHK(rbf_kuu(ctx->st, y.d.kernel_kind, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din, y.Kuu,
+                   train ? y.Euu : nullptr));
+  if (y.off_white >= 0) HIPCHK(add_diag_dev(ctx->st, y.Kuu, M, Mp, P(ctx, y.off_white)));
+  HIPCHK(copy_mat(ctx->st, y.Kuu, y.Lu, MM));
+  HIPCHK(potrf_inv(ctx->st, y.Lu, y.Linv, ctx->sm[9], Mp, 1, ctx->info, M));
+  HIPCHK(wcat_transpose(ctx->st, y.Linv, Mp, 1, y.LinvT));
+  if (y.d.white) {
+    HIPCHK(lq_to_wcat(ctx->st, y.Lq, Mp, D, y.Wcat));
+    HIPCHK(copy_mat(ctx->st, y.qmu_p, y.u, (long)Mp * D));
+  } else {
+    RET(G(ctx, 2, GEMM_NN, Mp, Mp, Mp, y.Linv, Mp, y.Lq, Mp, y.Wcat, (long)D * Mp, 1.0, 0, D, 0, MM, Mp));
+    RET(G(ctx, 2, GEMM_NN, Mp, D, Mp, y.Linv, Mp, y.qmu_p, D, y.u, D, 1.0, 0));
+  }
+  HIPCHK(layer_kl(ctx->st, y.Wcat, y.u, y.Lq, y.Lu, M, Mp, D, y.d.white, ctx->scal));
+  if (train) {
+    if (ctx->store_t) {
+      HIPCHK(wcat_transpose(ctx->st, y.Wcat, Mp, D, y.Scat));
+    } else {       // S'_d = W_d W_d^T - I  (symmetric), stacked [D*Mp x Mp]
+      GemmArgs a = mk(Mp, Mp, Mp, y.Wcat, (long)D * Mp, y.Wcat, (long)D * Mp, y.Scat, Mp);
+      a.batch = D; a.sA = Mp; a.sB = Mp; a.sC = MM;
+      RET(GX(ctx, 2, GEMM_NT, a));
+      HIPCHK(sub_identity(ctx->st, y.Scat, M, Mp, D));
+    }
+    HIPCHK(make_z1(ctx->st, P(ctx, y.off_Z), M, Mp, Din, y.Z1));
+  }
+  return DGP_OK;
+}
+
+// The chains of the layers above the first, each on a side stream, WITHOUT a join: forward_chunk waits for layer l's event
+// right before it needs that layer's matrices.  Called by forward_chunk once the first layer's forward kernels have been
+// ENQUEUED: a chain is ~35 launches, i.e. ~0.2 ms of host time, and with all of them issued up front the first forward
+// kernel reached the device 0.75-1 ms into the iteration (seen in the kernel trace of a small shard: the device idle while
+// the host was still issuing the upper layers' chains).
+int prep_deferred_layers(dgp_ctx* ctx) {
+  if (!ctx->prep_deferred) return DGP_OK;
+  ctx->prep_deferred = false;
+  const bool train = ctx->prep_deferred_train;
+  hipStream_t main_st = ctx->st;
+  for (size_t li = 1; li < ctx->L.size(); ++li) {
+    const int w = 1 + (int)((li - 1) % 2);
+    ctx->st = ctx->side[w - 1];
+    ctx->sm = ctx->smset[w];
+    const int r = prep_layer(ctx, li, train);
+    if (r == DGP_OK) { (void)hipEventRecord(ctx->ev_prep[li], ctx->st); ctx->prep_wait[li] = true; }
+    ctx->st = main_st;
+    ctx->sm = ctx->smset[0];
+    RET(r);
+  }
+  ctx->prep_level = train ? 2 : 1;        // every layer's chain has been enqueued
+  return DGP_OK;
+}
+
+// `overlap`: the first layer's chain on the context's stream now, the others deferred to prep_deferred_layers (the first
+// layer's forward pass covers them); without it all chains run at once on three workers and are joined here.
 int prep(dgp_ctx* ctx, bool train = false, bool overlap = false) {
   if (ctx->prep_level >= (train ? 2 : 1)) {        // parameters unchanged: keep the factorisation and the KL in scal[0]
     HIPCHK(hipMemsetAsync(ctx->scal + 1, 0, 3 * sizeof(double), ctx->st));
@@ -523,64 +585,59 @@ int prep(dgp_ctx* ctx, bool train = false, bool overlap = false) {
   }
   ctx->prep_level = 0;        // set only once every layer's chain has been enqueued: an error return below must not
                               // leave a half-built factorisation marked as current
+  ctx->prep_deferred = false;
   HIPCHK(hipMemsetAsync(ctx->scal, 0, 4 * sizeof(double), ctx->st));
   const bool ov = overlap && ctx->use_side && ctx->events_ok && ctx->L.size() > 1 && ctx->L.size() <= (size_t)dgp_ctx::kMaxEv;
-  hipStream_t main_st = ctx->st;
   if (ov) {
-    HIPCHK(hipEventRecord(ctx->ev_fork, main_st));
+    HIPCHK(hipEventRecord(ctx->ev_fork, ctx->st));      // (the side streams start behind the previous parameter update)
     for (int i = 0; i < 2; ++i) { HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0)); ctx->side_touched[i] = true; }
+    {
+      ProfScope ps(ctx, 2, 0, 0);
+      RET(prep_layer(ctx, 0, train));
+    }
+    ctx->prep_deferred = true;
+    ctx->prep_deferred_train = train;
+    return DGP_OK;
   }
   {
-  LayerFork fork(ctx, ov ? 1 : (int)ctx->L.size());
-  for (size_t li = 0; li < ctx->L.size(); ++li) {
-    Layer& y = ctx->L[li];
-    if (ov) {
-      const int w = li == 0 ? 0 : 1 + (int)((li - 1) % 2);
-      ctx->st = w == 0 ? main_st : ctx->side[w - 1];
-      ctx->sm = ctx->smset[w];
-    } else {
+    LayerFork fork(ctx, (int)ctx->L.size());
+    for (size_t li = 0; li < ctx->L.size(); ++li) {
       fork.use((int)li);
+      RET(prep_layer(ctx, li, train));
     }
-    struct Restore { dgp_ctx* c; hipStream_t m; bool on; size_t li; ~Restore() {
-      if (!on) return;
-      if (li > 0) { (void)hipEventRecord(c->ev_prep[li], c->st); c->prep_wait[li] = true; }
-      c->st = m; c->sm = c->smset[0]; } } restore{ctx, main_st, ov, li};
-    const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
-    const long MM = (long)Mp * Mp;
-    HIPCHK(pack_q(ctx->st, P(ctx, y.off_qsqrt), P(ctx, y.off_qmu), M, Mp, D, y.Lq, y.qmu_p));
-    if (y.d.kernel_kind == DGP_KERNEL_MF)
-      HIPCHK(mf_kuu(ctx->st, P(ctx, y.off_Z), P(ctx, y.off_var), M, Mp, Din, y.Kuu));
-    else
-      HIPCHK(rbf_kuu(ctx->st, y.d.kernel_kind, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din, y.Kuu,
-                     train ? y.Euu : nullptr));
-    if (y.off_white >= 0) HIPCHK(add_diag_dev(ctx->st, y.Kuu, M, Mp, P(ctx, y.off_white)));
-    HIPCHK(copy_mat(ctx->st, y.Kuu, y.Lu, MM));
-    HIPCHK(potrf_inv(ctx->st, y.Lu, y.Linv, ctx->sm[9], Mp, 1, ctx->info, M));
-    HIPCHK(wcat_transpose(ctx->st, y.Linv, Mp, 1, y.LinvT));
-    if (y.d.white) {
-      HIPCHK(lq_to_wcat(ctx->st, y.Lq, Mp, D, y.Wcat));
-      HIPCHK(copy_mat(ctx->st, y.qmu_p, y.u, (long)Mp * D));
-    } else {
-      RET(G(ctx, 2, GEMM_NN, Mp, Mp, Mp, y.Linv, Mp, y.Lq, Mp, y.Wcat, (long)D * Mp, 1.0, 0, D, 0, MM, Mp));
-      RET(G(ctx, 2, GEMM_NN, Mp, D, Mp, y.Linv, Mp, y.qmu_p, D, y.u, D, 1.0, 0));
-    }
-    HIPCHK(layer_kl(ctx->st, y.Wcat, y.u, y.Lq, y.Lu, M, Mp, D, y.d.white, ctx->scal));
-    if (train) {
-      if (ctx->store_t) {
-        HIPCHK(wcat_transpose(ctx->st, y.Wcat, Mp, D, y.Scat));
-      } else {       // S'_d = W_d W_d^T - I  (symmetric), stacked [D*Mp x Mp]
-        GemmArgs a = mk(Mp, Mp, Mp, y.Wcat, (long)D * Mp, y.Wcat, (long)D * Mp, y.Scat, Mp);
-        a.batch = D; a.sA = Mp; a.sB = Mp; a.sC = MM;
-        RET(GX(ctx, 2, GEMM_NT, a));
-        HIPCHK(sub_identity(ctx->st, y.Scat, M, Mp, D));
-      }
-      HIPCHK(make_z1(ctx->st, P(ctx, y.off_Z), M, Mp, Din, y.Z1));
-    }
-  }
   }   // the fork has joined the side streams
   ctx->prep_level = train ? 2 : 1;
   return DGP_OK;
 }
+
+// the deferred chains enqueued and every prep chain joined into the context's stream (callers that may not have run a
+// forward pass, which is what normally consumes both)
+int prep_flush(dgp_ctx* ctx) {
+  RET(prep_deferred_layers(ctx));
+  for (int l = 0; l < dgp_ctx::kMaxEv && l < (int)ctx->L.size(); ++l)
+    if (ctx->prep_wait[l]) { HIPCHK(hipStreamWaitEvent(ctx->st, ctx->ev_prep[l], 0)); ctx->prep_wait[l] = false; }
+  return DGP_OK;
+}
+
+// joins every side stream back into the context's stream on EVERY exit of dgp_grad_step / dgp_grad_partial (also error returns: chains or
+// all-reduces already enqueued on the side streams must not race with the next call's memset of the partial-sum buffer)
+struct SideJoin {
+  dgp_ctx* ctx;
+  hipStream_t main;
+  bool on;
+  ~SideJoin() {
+    if (!on) return;
+    ctx->st = main;
+    ctx->sm = ctx->smset[0];
+    for (int i = 0; i < dgp_ctx::kSide; ++i) {
+      if (!ctx->side_touched[i]) continue;
+      (void)hipEventRecord(ctx->ev_join[i], ctx->side[i]);
+      (void)hipStreamWaitEvent(main, ctx->ev_join[i], 0);
+      ctx->side_touched[i] = false;
+    }
+    for (int l = 0; l < dgp_ctx::kMaxEv; ++l) ctx->prep_wait[l] = false;   // (all prep chains are joined now)
+  }
+};
 
 ZSource zsrc_of(dgp_ctx* ctx, int l, bool use_zs, uint64_t seed, long n_goff, long Ntot) {
   ZSource z;
@@ -696,6 +753,7 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
                             zsrc_of(ctx, l, use_zs, seed, n_goff, Ntot), n0, y.mean, y.var, y.F, y.d.kernel_kind,
                             y.off_white >= 0 ? P(ctx, y.off_white) : nullptr));
     }
+    if (l == 0) RET(prep_deferred_layers(ctx));     // (after the first layer's launches: see there)
   }
   return DGP_OK;
 }

@@ -8,32 +8,50 @@ namespace dgp {
 // G[d] += sum of the partial triangles of d, in a fixed order (XCD by XCD, inside an XCD by workgroup index).  One
 // workgroup of 256 threads per (block, d): thread = lane * 4 + e.  Inside an XCD the workgroups whose ranges meet d's local
 // k-tiles [d KTx, (d + 1) KTx) are consecutive; only the first of them can have started in d - 1 (its partial of d is then
-// its SECOND segment).
-__global__ __launch_bounds__(256) void gram_reduce_kernel(GramArgs g, int grid) {
+// its SECOND segment).  Which workgroups those are is worked out on the host (GramReduceMap: a few hundred integer
+// divisions per launch; done per thread in the kernel they made it 0.15 ms instead of 0.02).
+struct GramReduceMap {
+  short i0[8][8], i1[8][8];      // [d][xcd]: workgroup indices idx (b = xcd + 8 idx) with a partial of d: [i0, i1)
+  unsigned char seg0[8][8];      // segment (0 / 1) of d in workgroup i0 (every later one: 0)
+};
+
+static GramReduceMap gram_reduce_map(long P, int D, int grid) {
+  GramReduceMap m{};
+  const long KT = P / 16;
+  for (int d = 0; d < D; ++d)
+    for (unsigned x = 0; x < 8u; ++x) {
+      m.i0[d][x] = m.i1[d][x] = 0; m.seg0[d][x] = 0;
+      if (x >= (unsigned)grid) continue;
+      const long n_x = grid / 8 + (x < (unsigned)grid % 8u ? 1 : 0);
+      const GramRange r0 = gram_range(KT, D, x, (unsigned)grid);       // (idx 0: the XCD's k-tile share)
+      if (r0.ktn <= 0) continue;
+      const long Fx = r0.ktn * D, lo = (long)d * r0.ktn, hi = lo + r0.ktn;
+      auto cut = [&](long i) { return (Fx * i) / n_x; };
+      long a = 0, b = n_x;
+      while (a < n_x && cut(a + 1) <= lo) ++a;            // first workgroup whose range ends after lo
+      while (b > a && cut(b - 1) >= hi) --b;             // one past the last whose range starts before hi
+      while (a < b && cut(a + 1) <= cut(a)) ++a;          // (empty ranges store nothing)
+      m.i0[d][x] = (short)a; m.i1[d][x] = (short)b;
+      m.seg0[d][x] = (unsigned char)(a < b ? d - (int)(cut(a) / r0.ktn) : 0);
+    }
+  return m;
+}
+
+__global__ __launch_bounds__(256) void gram_reduce_kernel(GramArgs g, GramReduceMap m) {
   const int id = blockIdx.x, d = blockIdx.y, t = threadIdx.x;
-  const long KT = g.P / 16;
   const double* __restrict__ w = g.ws + (long)id * 256 + t;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  for (unsigned x = 0; x < 8u && x < (unsigned)grid; ++x) {
-    const unsigned n_x = (unsigned)grid / 8u + (x < (unsigned)grid % 8u ? 1u : 0u);
-    const GramRange r0 = gram_range(KT, g.D, x, (unsigned)grid);       // (idx 0: the XCD's k-tile share)
-    const long Fx = r0.ktn * g.D, lo = (long)d * r0.ktn, hi = lo + r0.ktn;
-    if (r0.ktn <= 0) continue;
-    // first workgroup whose range ends after lo, first whose range starts at or after hi
-    long i0 = (lo * n_x) / Fx;
-    while (i0 > 0 && (Fx * i0) / n_x > lo) --i0;
-    while ((Fx * (i0 + 1)) / n_x <= lo) ++i0;
-    long i1 = (hi * n_x) / Fx;
-    if (i1 > (long)n_x) i1 = n_x;
-    while (i1 < (long)n_x && (Fx * i1) / n_x < hi) ++i1;
-    while (i1 > i0 + 1 && (Fx * (i1 - 1)) / n_x >= hi) --i1;
-    for (long i = i0; i < i1; ++i) {
-      const long f_lo = (Fx * i) / n_x, f_hi = (Fx * (i + 1)) / n_x;
-      if (f_hi <= f_lo) continue;                                       // (an empty range stores nothing)
-      const int seg = d - (int)(f_lo / r0.ktn);                         // 0: the range starts in d; 1: it started in d - 1
-      const double v = w[(((long)x + 8 * i) * 2 + seg) * GR_SLOT_DOUBLES];
-      switch ((i - i0) & 3) { case 0: s0 += v; break; case 1: s1 += v; break; case 2: s2 += v; break; default: s3 += v; break; }
+  for (int x = 0; x < 8; ++x) {
+    const int i0 = m.i0[d][x], i1 = m.i1[d][x];
+    if (i1 <= i0) continue;
+    s0 += w[(((long)x + 8 * i0) * 2 + m.seg0[d][x]) * GR_SLOT_DOUBLES];
+    int i = i0 + 1;
+    for (; i + 4 <= i1; i += 4) {                               // (four independent loads in flight; fixed association)
+      const double v0 = w[((long)x + 8 * (i + 0)) * 2 * GR_SLOT_DOUBLES], v1 = w[((long)x + 8 * (i + 1)) * 2 * GR_SLOT_DOUBLES];
+      const double v2 = w[((long)x + 8 * (i + 2)) * 2 * GR_SLOT_DOUBLES], v3 = w[((long)x + 8 * (i + 3)) * 2 * GR_SLOT_DOUBLES];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
     }
+    for (; i < i1; ++i) s0 += w[((long)x + 8 * i) * 2 * GR_SLOT_DOUBLES];
   }
   const double sum = (s0 + s1) + (s2 + s3);
   int r = 0;
@@ -94,7 +112,7 @@ hipError_t gemm_gram(hipStream_t st, const GemmArgs& a) {
   if (g.A) hipLaunchKernelGGL((gemm_gram_kernel<false, 2>), dim3(grid), dim3(512), 0, st, g);
   else if (g.s) hipLaunchKernelGGL((gemm_gram_kernel<true, 1>), dim3(grid), dim3(512), 0, st, g);
   else hipLaunchKernelGGL((gemm_gram_kernel<false, 1>), dim3(grid), dim3(512), 0, st, g);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(136, g.D), dim3(256), 0, st, g, (int)grid);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(136, g.D), dim3(256), 0, st, g, gram_reduce_map(g.P, g.D, (int)grid));
   return hipGetLastError();
 }
 
