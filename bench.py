@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "dgp-toolbox_amd"))
 
 import numpy as np  # noqa: E402
 
-FP64_MFMA_PEAK_TFLOPS = 78.6     # AMD MI355X fp64 matrix spec; issue-rate microbench in DESIGN.md
+FP64_MFMA_PEAK_TFLOPS = 78.6     # AMD MI355X fp64 matrix spec; issue-rate microbench in NOTES.md
 HBM_PEAK_GBS = 8000.0
 
 

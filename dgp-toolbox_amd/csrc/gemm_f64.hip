@@ -161,7 +161,7 @@ static hipError_t dispatch(hipStream_t st, const GemmArgs& a) {
 }
 
 // CUs the persistent kernels (one workgroup per CU: tall tiles, Gram) leave free.  A workgroup of theirs fills its CU, so
-// with one on every CU nothing else is scheduled until the kernel ends - which is fine for a single process (DESIGN.md
+// with one on every CU nothing else is scheduled until the kernel ends - which is fine for a single process (NOTES.md
 // par. 10: the L2 sharing of a full grid is worth more than the free CUs) but makes a collective issued beside the
 // backward pass wait for the end of a kernel.  dgp_comm_init sets it for its context (GemmArgs::reserve_cus).
 int gemm_device_cus(const GemmArgs& a) {

@@ -1,6 +1,6 @@
 // Tall-tile kernel for the forward T product  T_d = Ct * W_d  (+ |t_d|^2)  with W_d lower triangular, Mp = 256
 //   (layers.py:254-263, SK @ A in triangular form; the product gemm_wide.h runs as <DIR 2, EM 1>).
-// Why: per k-tile the wide-tile kernel costs its MFMA cycles + ~1050 (DESIGN.md par. 10).  Its 128 x 256 tile walks a
+// Why: per k-tile the wide-tile kernel costs its MFMA cycles + ~1050 (NOTES.md par. 10).  Its 128 x 256 tile walks a
 // triangular 256 x 256 block in 16 k-tiles of 1..8 column-block PAIRS (144 of 256 block-steps executed for 136 needed).
 // Here a tile is 256 rows x 128 columns: eight waves stacked over the rows, every wave across all eight 16-column blocks
 // of the tile, so that a k-tile t needs exactly the blocks cb <= t: the left half of a triangular block is 16 k-tiles of
