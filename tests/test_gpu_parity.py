@@ -162,7 +162,11 @@ def test_structurally_zero_q_sqrt_gradient_entries_are_rounding_noise():
     for i in range(2):
         g = np.asarray(G[(i, "q_sqrt")])[0]
         rms = float(np.sqrt(np.mean(g[sl] ** 2)))                           # exact value of every entry: 0
-        assert rms < 7e-11 and np.abs(g[sl]).max() < 1e-9, (i, rms, np.abs(g[sl]).max())
+        # the bound the trajectory tolerance rests on is the rms (tests/test_oracle.py derives 3e-4 from 7e-11); the largest of
+        # n = 300 entries of that rms is expected at rms * sqrt(2 ln n) = 3.4 rms (measured: 2.0e-10 at rms 3e-11..6e-11), so
+        # the max is bounded by 5 rms-bounds, not by a number of its own
+        n_ent = len(sl[0])
+        assert rms < 7e-11 and np.abs(g[sl]).max() < 7e-11 * 1.5 * np.sqrt(2 * np.log(n_ent)), (i, rms, np.abs(g[sl]).max())
         assert np.abs(np.diag(g)).max() > 1.0                               # next to diagonal entries of order 1e3
 
 
@@ -272,8 +276,9 @@ def test_adam_iterations_graph_replay_matches_call_by_call(natgrad):
                                      use_graph=1 if mode == "graph" else 0)
         res.append((el, ctx.params_get()))
     # (the split-K atomics make two runs of the SAME sequence differ in the last bits, and Adam's epsilon amplifies that
-    #  on this model, see test_nglast_trajectory_tolerance_is_amplified_rounding_noise: 1e-6 here; a wrong seed or step
-    #  count would show at 1e-2)
+    #  on this model: tests/test_oracle.py::test_graph_replay_tolerance_is_amplified_summation_order_noise derives on the
+    #  oracle that 1e-15-relative noise on the gradient moves these nine ELBOs by < 1e-7, linearly; 1e-6 = 10x that; a
+    #  wrong seed or step count would show at 1e-2)
     for el, th in res[1:]:
         np.testing.assert_allclose(el, res[0][0], rtol=1e-6)
         np.testing.assert_allclose(th, res[0][1], rtol=1e-5, atol=1e-7)

@@ -249,3 +249,59 @@ def test_nglast_trajectory_tolerance_is_amplified_rounding_noise():
     frozen = _nglast_trajectory(freeze_inner_q_sqrt=True)
     frozen_noisy = _nglast_trajectory(noise=1e-11, freeze_inner_q_sqrt=True)
     assert np.max(np.abs(frozen_noisy - frozen) / np.abs(frozen)) < 1e-10
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Where the 1e-6 of tests/test_gpu_parity.py::test_adam_iterations_graph_replay_matches_call_by_call comes from.
+# The three ways of running the same nine iterations issue the same kernels with the same seeds; what differs between two
+# runs is the order of the fp64 atomic adds of the split-K reductions of this small model.  On the oracle alone: noise of
+# relative size r (relative to the largest entry of a gradient block, i.e. also on the inner q_sqrt entries that are zero
+# in exact arithmetic) moves the nine printed ELBOs of the Adam-on-everything loop by 1.07e10 * r, linearly from r = 1e-17
+# to 1e-14: Adam (epsilon 1e-7, lr 1e-2) turns an entry of size 1e-16 * 1e5 into a step of 1e-6.  So 1e-6 is the response to
+# ONE rounding unit (1.1e-16) of the largest entry; the HIP path's own run-to-run spread was measured at 2e-9 (only the last
+# bits of a few partial sums move), a wrong seed or step count shows at 1e-2.  With the natural-gradient step owning
+# (q_mu, q_sqrt) the same noise moves the ELBOs by < 1e-10.
+def _replay_trajectory(rel_noise=0.0, seed=0, natgrad=False):
+    from dgp_oracle_train import OracleTrainer
+    from helpers import notebook_data
+    X, Y, Z = notebook_data()
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(1.0, [1.0]) for _ in range(3)], [1, 1], num_samples=10)
+    for l in mo.layers[:-1]:
+        l.q_sqrt = l.q_sqrt * 1e-2
+    tr = OracleTrainer(mo, base_seed=100)
+    if natgrad:
+        for i in range(3):
+            tr.trainable[(i, "q_mu")] = False
+            tr.trainable[(i, "q_sqrt")] = False
+    if rel_noise:
+        rng = np.random.default_rng(seed)
+
+        def hook(flat):
+            for k, g in flat.items():
+                g = np.asarray(g)
+                if g.ndim == 0:
+                    continue
+                g += rel_noise * (np.abs(g) + np.abs(g).max()) * rng.standard_normal(g.shape)
+        tr.grad_hook = hook
+    adam = tr.new_adam(0.01, 0.9, 0.999, 1e-7)
+    out = []
+    for _ in range(9):
+        out.append(tr.adam_iteration(adam))
+        if natgrad:
+            tr.natgrad_iteration(0.01, [0, 1, 2])
+    return np.array(out)
+
+
+@pytest.mark.parametrize("natgrad", [False, True])
+def test_graph_replay_tolerance_is_amplified_summation_order_noise(natgrad):
+    base = _replay_trajectory(natgrad=natgrad)
+    spread = {}
+    for noise in (1e-16, 1e-15):
+        spread[noise] = max(np.max(np.abs(_replay_trajectory(noise, seed, natgrad) - base) / np.abs(base)) for seed in (0, 1))
+    if natgrad:
+        assert max(spread.values()) < 1e-9, spread
+        return
+    amp = spread[1e-15] / 1e-15
+    assert 3e9 < amp < 3e10, spread                                   # measured 1.07e10
+    assert 5.0 < spread[1e-15] / spread[1e-16] < 20.0, spread        # linear
+    assert 0.3e-6 < amp * 1.1e-16 < 3e-6                              # the GPU test's 1e-6 = one rounding unit of the largest entry
