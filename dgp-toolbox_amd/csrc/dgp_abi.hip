@@ -36,6 +36,8 @@ int dgp_create(int device, void* hip_stream, dgp_ctx** out) {
     ctx->use_side = !(e && e[0] == '0');
     const char* t = getenv("DGP_STORE_T");
     ctx->store_t = !(t && t[0] == '0');
+    const char* ch = getenv("DGP_CHAIN");
+    ctx->chain_on = ch && ch[0] == '1';
     const char* bt = getenv("DGP_BLOCKED_T");
     ctx->blocked_t = !(bt && bt[0] == '0');
     bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -521,14 +523,16 @@ int dgp_acc_info(dgp_ctx* ctx, void** device_ptr, int64_t* n_doubles) {
 
 int dgp_acc_bind(dgp_ctx* ctx, void* external_device_ptr) {
   if (!ctx || ctx->L.empty()) return fail(ctx, DGP_ERR_INVALID, "dgp_acc_bind: no model");
-  ctx->acc = external_device_ptr ? reinterpret_cast<double*>(external_device_ptr) : ctx->acc_own;
+  double* acc = external_device_ptr ? reinterpret_cast<double*>(external_device_ptr) : ctx->acc_own;
+  if (acc != ctx->acc) drop_chains(ctx);       // (the buffer's address is part of the recorded finish chains)
+  ctx->acc = acc;
   return DGP_OK;
 }
 
 // Small-matrix chain of ONE layer after its point sums are final (and summed over the ranks): Cholesky backward, KL
 // gradient, kernel-hyper-parameter gradients -> that layer's entries of d ELBO / d params.  Launches on ctx->st with the
 // scratch set ctx->sm (the caller selects a side stream + its scratch for concurrent layers).
-static int finish_layer(dgp_ctx* ctx, size_t li) {
+static int finish_layer_launches(dgp_ctx* ctx, size_t li) {
   double* acc = ctx->acc;
   double* g = ctx->grad;
     Layer& y = ctx->L[li];
@@ -553,16 +557,19 @@ static int finish_layer(dgp_ctx* ctx, size_t li) {
     if (!y.d.white) {
       RET(G(ctx, 2, GEMM_NT, Mp, Mp, D, du, D, y.u, D, T1, Mp, 1.0, 0));
       // K = D*Mp against an Mp x Mp output: split the reduction so that more than a handful of workgroups run
-      RET(G(ctx, 2, GEMM_NT, Mp, Mp, DM, dW, DM, y.Wcat, DM, T1, Mp, 1.0, 1, 1, 0, 0, 0, D > 1 ? D : 1));
+      if (Mp <= 64) {      // small models: D accumulating one-workgroup products (recordable as chain steps, fixed order)
+        for (int d = 0; d < D; ++d)
+          RET(G(ctx, 2, GEMM_NT, Mp, Mp, Mp, dW + (long)d * Mp, DM, y.Wcat + (long)d * Mp, DM, T1, Mp, 1.0, 1));
+      } else {
+        RET(G(ctx, 2, GEMM_NT, Mp, Mp, DM, dW, DM, y.Wcat, DM, T1, Mp, 1.0, 1, 1, 0, 0, 0, D > 1 ? D : 1));
+      }
       RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Linv, Mp, T1, Mp, T2, Mp, 1.0, 0));
       RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Linv, Mp, dW, DM, y.dLq, Mp, 1.0, 0, D, 0, Mp, MM));
       RET(G(ctx, 2, GEMM_TN, Mp, D, Mp, y.Linv, Mp, du, D, y.dqmu_p, D, 1.0, 0));
       HIPCHK(lubar_finish(ctx->st, Q, T2, y.Lu, M, Mp, D, 0));
     } else {
       // W_d = L_q,d, u = q_mu: gradients pass straight through
-      for (int d = 0; d < D; ++d)
-        HIPCHK(hipMemcpy2DAsync(y.dLq + (long)d * MM, Mp * 8, dW + (long)d * Mp, DM * 8, Mp * 8, Mp,
-                                hipMemcpyDeviceToDevice, ctx->st));
+      for (int d = 0; d < D; ++d) HIPCHK(copy_2d(ctx->st, dW + (long)d * Mp, DM, y.dLq + (long)d * MM, Mp, Mp, Mp));
       HIPCHK(copy_mat(ctx->st, du, y.dqmu_p, (long)Mp * D));
       HIPCHK(lubar_finish(ctx->st, Q, nullptr, y.Lu, M, Mp, D, 1));
     }
@@ -584,6 +591,10 @@ static int finish_layer(dgp_ctx* ctx, size_t li) {
     if (y.off_white >= 0) HIPCHK(white_grad(ctx->st, Sm, M, Mp, acc + y.acc_dvar, g + y.off_white));
     HIPCHK(unpack_q_grads(ctx->st, y.dLq, y.dqmu_p, M, Mp, D, g + y.off_qsqrt, g + y.off_qmu));
   return DGP_OK;
+}
+
+static int finish_layer(dgp_ctx* ctx, size_t li) {
+  return run_chain(ctx, CHAIN_FINISH, li, [&]() { return finish_layer_launches(ctx, li); });
 }
 
 static int finish_tail(dgp_ctx* ctx) {

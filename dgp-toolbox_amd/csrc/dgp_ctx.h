@@ -26,6 +26,8 @@
 #include <vector>
 
 #include "dgp_internal.h"
+#include "chain.h"
+#include <map>
 
 using namespace dgp;
 
@@ -131,6 +133,11 @@ struct dgp_ctx {
   bool events_ok = false;   // every stream and event above exists (tested wherever the side path is taken)
   bool prep_wait[kMaxEv] = {false};
   bool side_touched[kSide] = {false};
+  // recorded small-kernel chains (chain.h): key = (chain kind, layer, scratch set) -> program in device memory; n < 0: this
+  // chain contains a launch that cannot be recorded and runs launch by launch
+  struct ChainProg { ChainOp* dev = nullptr; int n = 0; };
+  std::map<long, ChainProg> chains;
+  bool chain_on = false;    // off: measured slower than launch by launch (NOTES.md, round 3); DGP_CHAIN=1 enables
   bool prep_deferred = false, prep_deferred_train = false;   // the upper layers' prep chains are still to be enqueued (prep_deferred_layers)
   // the backward pass's HBM-bound part on a low-priority stream beside its matrix-core-bound reductions (backward_chunk)
   hipStream_t bst = nullptr;
@@ -201,7 +208,7 @@ struct ProfScope {
   size_t slot;
   ProfScope(dgp_ctx* c, int cat, double flops, double bytes) : ctx(c), active(false), slot(0) {
     Prof& p = c->prof;
-    if (!p.on) return;
+    if (!p.on || chain_recorder()) return;
     p.flops[cat] += flops;
     p.bytes[cat] += bytes;
     if (p.depth++ > 0) return;          // nested scopes are covered by the outermost one
@@ -223,7 +230,7 @@ struct ProfScope {
   }
   ~ProfScope() {
     Prof& p = ctx->prof;
-    if (!p.on) return;
+    if (!p.on || chain_recorder()) return;
     if (active) (void)hipEventRecord(p.ev[2 * slot + 1], ctx->st);
     if (p.depth > 0) --p.depth;
   }
@@ -381,8 +388,10 @@ void drop_graph(dgp_ctx* ctx) {
   ctx->graph_exec = nullptr; ctx->graph = nullptr; ctx->graph_key.clear();
 }
 
+void drop_chains(dgp_ctx* ctx);
 void free_model(dgp_ctx* ctx) {
   drop_graph(ctx);
+  drop_chains(ctx);
   ctx->ws_key_N = -1;
   ctx->prep_level = 0;
   for (auto& l : ctx->L) {
@@ -514,9 +523,53 @@ int upload_zs(dgp_ctx* ctx, const double* const* zs, int S, long Ntot) {
 
 inline const double* P(dgp_ctx* ctx, long off) { return ctx->params + off; }
 
+// ------------------------------------------------------------------------------- recorded chains (small models)
+enum ChainKind : int { CHAIN_PREP = 0, CHAIN_PREP_TRAIN = 1, CHAIN_FINISH = 2 };
+
+bool chain_eligible(const dgp_ctx* ctx, const Layer& y) {
+  return ctx->chain_on && !ctx->capturing && y.Mp <= 64 && y.d.D_out <= 64 && y.d.kernel_kind != DGP_KERNEL_MF && y.off_white < 0;
+}
+
+void drop_chains(dgp_ctx* ctx) {
+  for (auto& kv : ctx->chains) if (kv.second.dev) (void)hipFree(kv.second.dev);
+  ctx->chains.clear();
+}
+
+// Runs `enqueue` (a function that issues one layer's chain on ctx->st) as ONE launch: the first time the launches are
+// recorded instead of issued and the list is uploaded; afterwards chain_exec replays it.  Every pointer a chain touches
+// (parameters, the layer's matrices, the scratch set, the partial-sum buffer, the gradient) is fixed until the model or
+// the bound buffers change (free_model / dgp_acc_bind drop the programs).
+template <class F>
+int run_chain(dgp_ctx* ctx, int kind, size_t li, F&& enqueue) {
+  if (!chain_eligible(ctx, ctx->L[li])) return enqueue();
+  int w = 0;
+  for (int i = 0; i < dgp_ctx::kSide; ++i) if (ctx->sm == ctx->smset[i]) w = i;
+  const long key = ((long)kind * 1024 + (long)li) * 8 + w;
+  auto it = ctx->chains.find(key);
+  if (it == ctx->chains.end()) {
+    ChainRec rec;
+    chain_set_recorder(&rec);
+    const int r = enqueue();
+    chain_set_recorder(nullptr);
+    dgp_ctx::ChainProg prog;
+    if (r != DGP_OK || rec.failed || rec.ops.empty()) {
+      prog.n = -1;                               // not recordable (nothing was launched): launch by launch from now on
+    } else {
+      prog.n = (int)rec.ops.size();
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&prog.dev), rec.ops.size() * sizeof(ChainOp)));
+      HIPCHK(hipMemcpy(prog.dev, rec.ops.data(), rec.ops.size() * sizeof(ChainOp), hipMemcpyHostToDevice));
+    }
+    it = ctx->chains.emplace(key, prog).first;
+  }
+  if (it->second.n < 0) return enqueue();
+  ProfScope ps(ctx, 2, 0, 0);
+  HIPCHK(chain_exec(ctx->st, it->second.dev, it->second.n));
+  return DGP_OK;
+}
+
 // ------------------------------------------------------------------------------- prep: small matrices + KL
 // One layer's chain (Kuu, Cholesky + inverse, W, u, KL, the backward's transposes) on ctx->st with the scratch set ctx->sm.
-int prep_layer(dgp_ctx* ctx, size_t li, bool train) {
+int prep_layer_launches(dgp_ctx* ctx, size_t li, bool train) {
   Layer& y = ctx->L[li];
   const int M = y.d.M, Mp = y.Mp, D = y.d.D_out, Din = y.d.D_in;
   const long MM = (long)Mp * Mp;
@@ -550,6 +603,10 @@ int prep_layer(dgp_ctx* ctx, size_t li, bool train) {
     HIPCHK(make_z1(ctx->st, P(ctx, y.off_Z), M, Mp, Din, y.Z1));
   }
   return DGP_OK;
+}
+
+int prep_layer(dgp_ctx* ctx, size_t li, bool train) {
+  return run_chain(ctx, train ? CHAIN_PREP_TRAIN : CHAIN_PREP, li, [&]() { return prep_layer_launches(ctx, li, train); });
 }
 
 // The chains of the layers above the first, each on a side stream, WITHOUT a join: forward_chunk waits for layer l's event

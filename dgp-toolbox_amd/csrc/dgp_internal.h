@@ -71,6 +71,7 @@ hipError_t pack_q(hipStream_t st, const double* q_sqrt, const double* q_mu, int 
 // Wcat[k][d*Mp+n] <- Lq[d][k][n]   (white case: W_d = q_sqrt_d)
 hipError_t lq_to_wcat(hipStream_t st, const double* Lq, int Mp, int D, double* Wcat);
 hipError_t copy_mat(hipStream_t st, const double* src, double* dst, long n);
+hipError_t copy_2d(hipStream_t st, const double* src, long lds, double* dst, long ldd, int nr, int nc);   // dst[r][c] = src[r][c]
 // KL of one layer (layers.py:280-308) from W, u, diag(Lq), diag(Lu); adds into *kl_out (device)
 hipError_t layer_kl(hipStream_t st, const double* Wcat, const double* u, const double* Lq, const double* Lu, int M,
                     int Mp, int D, int white, double* kl_out);

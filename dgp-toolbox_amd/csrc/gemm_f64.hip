@@ -1,6 +1,7 @@
 // Host-side dispatch of the fp64 MFMA GEMM engine (see gemm_f64.h).
 #include "gemm_f64.h"
 #include "gemm_wide.h"
+#include "chain.h"
 #include <cstdlib>
 #include <algorithm>
 
@@ -195,6 +196,11 @@ hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args) {
   GemmArgs a = args;
   if (a.splits < 1) a.splits = 1;
   if (a.batch < 1) a.batch = 1;
+  if (ChainRec* r = chain_recorder()) {
+    // inside a recording (chain.h) only the one-workgroup product can become a step; anything else must not be issued
+    // out of order: the recording is marked unusable and its owner falls back to launch by launch
+    if (gemm_engine_of(op, a) != 5) { r->failed = true; return hipSuccess; }
+  }
   switch (gemm_engine_of(op, a)) {
     case 5: return gemm_small(st, op, a);
     case 2: return gemm_tall(st, a);

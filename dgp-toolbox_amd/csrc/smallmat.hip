@@ -3,39 +3,17 @@
 // natural-gradient step.  Reference: layers.py:227-234 (Kuu + jitter, Cholesky), layers.py:280-308
 // (KL), gpflow NaturalGradient [ext] (dgp.py:312,343).  Latency-bound work: M <= 1024.
 #include "dgp_internal.h"
+#include "chain_bodies.h"
 
 namespace dgp {
 
 #define LAUNCH_CHECK() return hipGetLastError()
 
 // ---------------------------------------------------------------------------------------- Kuu
-__global__ void rbf_kuu_kernel(int kind, const double* __restrict__ Z, const double* __restrict__ var,
-                               const double* __restrict__ ls, int M, int Mp, int Din, double* __restrict__ Kuu,
-                               double* __restrict__ Euu) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)Mp * Mp) return;
-  const int m = (int)(idx / Mp), n = (int)(idx % Mp);
-  double v, e = 0.0;
-  if (m < M && n < M) {
-    double r2 = 0.0;
-    for (int j = 0; j < Din; ++j) {
-      const double d = (Z[(long)m * Din + j] - Z[(long)n * Din + j]) / ls[j];
-      r2 += d * d;
-    }
-    stationary_k(kind, var[0], r2, v, e);
-    v += (m == n ? kJitter : 0.0);
-  } else {
-    v = (m == n) ? 1.0 : 0.0;
-  }
-  Kuu[idx] = v;
-  if (Euu) Euu[idx] = e;
-}
-
 hipError_t rbf_kuu(hipStream_t st, int kind, const double* Z, const double* var, const double* ls, int M, int Mp, int Din,
                    double* Kuu, double* Euu) {
   const long n = (long)Mp * Mp;
-  hipLaunchKernelGGL(rbf_kuu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, kind, Z, var, ls, M, Mp, Din, Kuu,
-                     Euu);
+  (void)chain_launch<CK_RBF_KUU>(st, dim3((unsigned)((n + 255) / 256)), kind, Z, var, ls, M, Mp, Din, Kuu, Euu);
   LAUNCH_CHECK();
 }
 
@@ -55,106 +33,11 @@ constexpr int LEAF = 64;
 //   Inverse : rows of L are scaled to a unit diagonal (L' = D^-1 L), X' = L'^-1 by forward substitution IN PLACE
 //             (entry k of a row is consumed by step k and replaced by the entry of X'), then X = X' D^-1.
 // Global reads and writes go row by row with the lanes along the row (coalesced) through an LDS transpose.
-__device__ __forceinline__ double lane_bcast(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
 
 // LF = 64: the leaf of the recursion.  LF = 32: models with at most 32 inducing points (the Bayesian-optimisation
 // surrogates; Mp = 64 with an identity padding): a quarter of the dependent readlane / fma chain (57 -> 16 us), the padding
 // rows [n, npad) of X are written as identity rows.
-template <int LF>
-__global__ __launch_bounds__(64) void leaf_potrf_inv_kernel(double* __restrict__ Aall, double* __restrict__ Xall, int ld,
-                                                            long stride, int off, int n, int do_chol,
-                                                            int* __restrict__ info, int npad) {
-  __shared__ double T[LF][LF + 1];
-  double* A = Aall + (long)blockIdx.x * stride + (long)off * ld + off;
-  double* X = Xall + (long)blockIdx.x * stride + (long)off * ld + off;
-  const int i = threadIdx.x;
-  for (int r = 0; r < n; ++r)
-    if (i < n) T[r][i] = A[(long)r * ld + i];
-  __syncthreads();
-  double a[LF];
-  // rows and columns beyond n behave as an identity block
-#pragma unroll
-  for (int j = 0; j < LF; ++j) {
-    const double v = T[i < n ? i : 0][j];
-    a[j] = (i < n && j < n) ? (j <= i ? v : 0.0) : (i == j ? 1.0 : 0.0);
-  }
-  double diag = 1.0;
-  if (do_chol) {
-    bool bad = false;
-#pragma unroll
-    for (int c = 0; c < LF; ++c) {
-      const double piv = lane_bcast(a[c], c);
-      // 1/sqrt(pivot): hardware estimate + two Newton steps (a library sqrt and a division are ~40 dependent
-      // fp64 operations on the critical path of every column)
-      double rs = __builtin_amdgcn_rsq(piv);
-      rs = rs * (1.5 - 0.5 * piv * rs * rs);
-      rs = rs * (1.5 - 0.5 * piv * rs * rs);
-      if (!(piv > 0.0)) { rs = nan(""); bad = true; }
-      const double l = (i >= c) ? a[c] * rs : 0.0;       // column c of L (zero above the diagonal)
-      a[c] = l;
-      if (i == c) diag = l;
-#pragma unroll
-      for (int j = c + 1; j < LF; ++j) a[j] = fma(-l, lane_bcast(l, j), a[j]);   // only j <= i is meaningful
-    }
-    if (bad && i == 0) atomicOr(info, 1);
-    __syncthreads();
-    if (i < LF)
-#pragma unroll
-      for (int j = 0; j < LF; ++j) T[i][j] = a[j];
-    __syncthreads();
-    for (int r = 0; r < n; ++r)
-      if (i < n) A[(long)r * ld + i] = T[r][i];
-  } else {
-#pragma unroll
-    for (int j = 0; j < LF; ++j) diag = (i == j) ? a[j] : diag;
-  }
-  const double dinv = 1.0 / diag;
-#pragma unroll
-  for (int k = 0; k < LF; ++k) a[k] = (i > k) ? a[k] * dinv : 0.0;      // strictly lower part of L' = D^-1 L
-#pragma unroll
-  for (int k = 0; k < LF; ++k) {
-    const double m = a[k];                                  // L'[i][k] for the rows below k, 0 for the others
-#pragma unroll
-    for (int j = 0; j < k; ++j) a[j] = fma(-m, lane_bcast(a[j], k), a[j]);   // row k of X' is final in lane k
-    a[k] = -m;
-  }
-#pragma unroll
-  for (int j = 0; j < LF; ++j) {
-    const double dj = lane_bcast(dinv, j);
-    a[j] = (i > j) ? a[j] * dj : (i == j ? dinv : 0.0);
-  }
-  __syncthreads();
-  if (i < LF)
-#pragma unroll
-    for (int j = 0; j < LF; ++j) T[i][j] = a[j];
-  __syncthreads();
-  for (int r = 0; r < n; ++r)
-    if (i < n) X[(long)r * ld + i] = T[r][i];
-  // identity padding of X (and zeros beside it) when the factorisation covers only the leading n of npad rows
-  for (int r = 0; r < npad; ++r)
-    if (i < npad && (r >= n || i >= n)) X[(long)r * ld + i] = (r == i) ? 1.0 : 0.0;
-}
-
 // batched strided block copy: dst[b][r][c] = src[b][r][c] for an nr x nc block (leading dimension ld, batch stride)
-__global__ void copy_block_kernel(const double* __restrict__ src, double* __restrict__ dst, int ld, long stride, int nr,
-                                  int nc) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)nr * nc) return;
-  const long o = (long)blockIdx.y * stride + (idx / nc) * ld + idx % nc;
-  dst[o] = src[o];
-}
-
-__global__ void zero_block_kernel(double* __restrict__ Aall, int ld, long stride, int r0, int c0, int nr, int nc) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)nr * nc) return;
-  double* A = Aall + (long)blockIdx.y * stride;
-  A[(long)(r0 + idx / nc) * ld + c0 + idx % nc] = 0.0;
-}
-
 static hipError_t sub_gemm(hipStream_t st, GemmOp op, long M, long N, long K, const double* A, const double* B, double* C,
                            int ld, long stride, int batch, double alpha, int beta, long sA = -1, long sB = -1) {
   GemmArgs g;
@@ -169,7 +52,7 @@ static hipError_t potrf_inv_rec(hipStream_t st, double* A, double* X, double* tm
                                 int n, int do_chol, int* info) {
   hipError_t e;
   if (n <= LEAF) {
-    hipLaunchKernelGGL(leaf_potrf_inv_kernel<LEAF>, dim3(batch), dim3(64), 0, st, A, X, ld, stride, off, n, do_chol, info, 0);
+    (void)chain_launch<CK_LEAF64>(st, dim3(batch), A, X, ld, stride, off, n, do_chol, info, 0);
     return hipGetLastError();
   }
   int n1 = ((n / 2 + 15) / 16) * 16;
@@ -191,7 +74,7 @@ static hipError_t potrf_inv_rec(hipStream_t st, double* A, double* X, double* tm
     // A21 <- L21 : copy T -> A21 as  A21 = T * I  is wasteful; use a strided 2D copy per batch
     {
       const long nc = (long)n2 * n1;
-      hipLaunchKernelGGL(copy_block_kernel, dim3((unsigned)((nc + 255) / 256), batch), dim3(256), 0, st, T, A21, ld, stride, n2, n1);
+      (void)chain_launch<CK_COPY_BLOCK>(st, dim3((unsigned)((nc + 255) / 256), batch), T, A21, ld, stride, n2, n1);
       if ((e = hipGetLastError()) != hipSuccess) return e;
     }
   }
@@ -202,14 +85,14 @@ static hipError_t potrf_inv_rec(hipStream_t st, double* A, double* X, double* tm
   // clean upper-right blocks (structural zeros are relied upon by the triangular hints of the GEMMs)
   const long nz = (long)n1 * n2;
   if (do_chol)
-    hipLaunchKernelGGL(zero_block_kernel, dim3((unsigned)((nz + 255) / 256), batch), dim3(256), 0, st, A, ld, stride, off, off + n1, n1, n2);
-  hipLaunchKernelGGL(zero_block_kernel, dim3((unsigned)((nz + 255) / 256), batch), dim3(256), 0, st, X, ld, stride, off, off + n1, n1, n2);
+    (void)chain_launch<CK_ZERO_BLOCK>(st, dim3((unsigned)((nz + 255) / 256), batch), A, ld, stride, off, off + n1, n1, n2);
+  (void)chain_launch<CK_ZERO_BLOCK>(st, dim3((unsigned)((nz + 255) / 256), batch), X, ld, stride, off, off + n1, n1, n2);
   return hipGetLastError();
 }
 
 hipError_t potrf_inv(hipStream_t st, double* A, double* X, double* tmp, int Mp, int batch, int* info, int n_act) {
   if (Mp <= LEAF && n_act > 0 && n_act <= 32) {      // A = blockdiag(A[:n, :n], I): only the leading block is factorised
-    hipLaunchKernelGGL(leaf_potrf_inv_kernel<32>, dim3(batch), dim3(64), 0, st, A, X, Mp, (long)Mp * Mp, 0, n_act, 1, info, Mp);
+    (void)chain_launch<CK_LEAF32>(st, dim3(batch), A, X, Mp, (long)Mp * Mp, 0, n_act, 1, info, Mp);
     return hipGetLastError();
   }
   return potrf_inv_rec(st, A, X, tmp, Mp, (long)Mp * Mp, batch, 0, Mp, 1, info);
@@ -220,29 +103,10 @@ hipError_t trinv_lower(hipStream_t st, const double* L, double* X, double* tmp, 
 }
 
 // ---------------------------------------------------------------------------------------- packing
-__global__ void pack_q_kernel(const double* __restrict__ q_sqrt, const double* __restrict__ q_mu, int M, int Mp, int D,
-                              double* __restrict__ Lq, double* __restrict__ qmu_p) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long nL = (long)D * Mp * Mp;
-  if (idx < nL) {
-    const int d = (int)(idx / ((long)Mp * Mp));
-    const int i = (int)((idx / Mp) % Mp), j = (int)(idx % Mp);
-    double v;
-    if (i < M && j < M) v = (j <= i) ? q_sqrt[((long)d * M + i) * M + j] : 0.0;
-    else v = (i == j) ? 1.0 : 0.0;
-    Lq[idx] = v;
-  }
-  if (idx < (long)Mp * D) {
-    const int i = (int)(idx / D), d = (int)(idx % D);
-    qmu_p[idx] = (i < M) ? q_mu[(long)i * D + d] : 0.0;
-  }
-}
-
 hipError_t pack_q(hipStream_t st, const double* q_sqrt, const double* q_mu, int M, int Mp, int D, double* Lq,
                   double* qmu_p) {
   const long n = (long)D * Mp * Mp;
-  hipLaunchKernelGGL(pack_q_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q_sqrt, q_mu, M, Mp, D, Lq,
-                     qmu_p);
+  (void)chain_launch<CK_PACK_Q>(st, dim3((unsigned)((n + 255) / 256)), q_sqrt, q_mu, M, Mp, D, Lq, qmu_p);
   LAUNCH_CHECK();
 }
 
@@ -265,155 +129,71 @@ hipError_t store_q(hipStream_t st, const double* Lq, const double* qmu_p, int M,
   LAUNCH_CHECK();
 }
 
-__global__ void lq_to_wcat_kernel(const double* __restrict__ Lq, int Mp, int D, double* __restrict__ Wcat) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)D * Mp * Mp) return;
-  const int d = (int)(idx / ((long)Mp * Mp));
-  const int k = (int)((idx / Mp) % Mp), n = (int)(idx % Mp);
-  Wcat[(long)k * D * Mp + (long)d * Mp + n] = Lq[idx];
-}
-
 hipError_t lq_to_wcat(hipStream_t st, const double* Lq, int Mp, int D, double* Wcat) {
   const long n = (long)D * Mp * Mp;
-  hipLaunchKernelGGL(lq_to_wcat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Lq, Mp, D, Wcat);
+  (void)chain_launch<CK_LQ_TO_WCAT>(st, dim3((unsigned)((n + 255) / 256)), Lq, Mp, D, Wcat);
   LAUNCH_CHECK();
 }
 
-__global__ void copy_kernel(const double* __restrict__ s, double* __restrict__ d, long n) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) d[i] = s[i];
+hipError_t copy_2d(hipStream_t st, const double* src, long lds, double* dst, long ldd, int nr, int nc) {
+  const long n = (long)nr * nc;
+  (void)chain_launch<CK_COPY2D>(st, dim3((unsigned)((n + 255) / 256)), src, lds, dst, ldd, nr, nc);
+  LAUNCH_CHECK();
 }
 hipError_t copy_mat(hipStream_t st, const double* src, double* dst, long n) {
-  hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+  (void)chain_launch<CK_COPY>(st, dim3((unsigned)((n + 255) / 256)), src, dst, n);
   LAUNCH_CHECK();
 }
 
-__global__ void make_z1_kernel(const double* __restrict__ Z, int M, int Mp, int Din, double* __restrict__ Z1) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int w = Din + 1;
-  if (idx >= (long)Mp * w) return;
-  const int m = (int)(idx / w), j = (int)(idx % w);
-  Z1[idx] = (m < M) ? (j < Din ? Z[(long)m * Din + j] : 1.0) : 0.0;
-}
 hipError_t make_z1(hipStream_t st, const double* Z, int M, int Mp, int Din, double* Z1) {
   const long n = (long)Mp * (Din + 1);
-  hipLaunchKernelGGL(make_z1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Z, M, Mp, Din, Z1);
+  (void)chain_launch<CK_MAKE_Z1>(st, dim3((unsigned)((n + 255) / 256)), Z, M, Mp, Din, Z1);
   LAUNCH_CHECK();
 }
 
 // writes (not accumulates) the Kuf + K_diag parts of d ELBO / d (Z, lengthscales, variance); one block per j
-__global__ __launch_bounds__(256) void rbf_kuf_bwd_finish_kernel(const double* __restrict__ GX, const double* __restrict__ x2rs,
-                                                                 const double* __restrict__ vsum, const double* __restrict__ Z,
-                                                                 const double* __restrict__ var, const double* __restrict__ ls,
-                                                                 int M, int Din, double* __restrict__ dZ,
-                                                                 double* __restrict__ dls, double* __restrict__ dvar,
-                                                                 const double* __restrict__ kdot) {
-  __shared__ double sh[16];
-  const int j = blockIdx.x, w = Din + 1;
-  const double l = ls[j];
-  double la = 0.0, va = 0.0;
-  for (int m = threadIdx.x; m < M; m += blockDim.x) {
-    const double cs = GX[(long)m * w + Din], gx = GX[(long)m * w + j], z = Z[(long)m * Din + j];
-    dZ[(long)m * Din + j] = -(z * cs - gx) / (l * l);
-    la += z * z * cs - 2.0 * z * gx;
-    va += cs;
-  }
-  for (int o = 32; o > 0; o >>= 1) { la += __shfl_down(la, o); va += __shfl_down(va, o); }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (lane == 0) { sh[wv] = la; sh[8 + wv] = va; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double lt = 0.0, vt = 0.0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { lt += sh[i]; vt += sh[8 + i]; }
-    dls[j] = (lt + x2rs[j]) / (l * l * l);
-    if (j == 0) dvar[0] = (kdot ? kdot[0] : vt) / var[0] + vsum[0];
-  }
-}
 hipError_t rbf_kuf_bwd_finish(hipStream_t st, const double* GX, const double* x2rs, const double* vsum, const double* Z,
                               const double* var, const double* ls, int M, int Din, double* dZ, double* dls, double* dvar,
                               const double* kdot) {
-  hipLaunchKernelGGL(rbf_kuf_bwd_finish_kernel, dim3(Din), dim3(256), 0, st, GX, x2rs, vsum, Z, var, ls, M, Din, dZ, dls, dvar,
-                     kdot);
+  (void)chain_launch<CK_KUF_BWD_FINISH>(st, dim3(Din), GX, x2rs, vsum, Z, var, ls, M, Din, dZ, dls, dvar, kdot);
   LAUNCH_CHECK();
 }
 
-__global__ __launch_bounds__(256) void lower_dot_kernel(const double* __restrict__ Lu, const double* __restrict__ Q, int M,
-                                                        int Mp, double* __restrict__ out) {
-  __shared__ double sh[4];
-  double a = 0.0;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)M * M; idx += (long)gridDim.x * blockDim.x) {
-    const int i = (int)(idx / M), j = (int)(idx % M);
-    if (j <= i) a += Lu[(long)i * Mp + j] * Q[(long)i * Mp + j];
-  }
-  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
-  __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
-}
 hipError_t lower_dot(hipStream_t st, const double* Lu, const double* Q, int M, int Mp, double* out) {
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(lower_dot_kernel, dim3(16), dim3(256), 0, st, Lu, Q, M, Mp, out);
+  if (chain_recorder()) {
+    (void)chain_launch<CK_ZERO1>(st, dim3(1), out, 1L);
+  } else {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
+    if (e != hipSuccess) return e;
+  }
+  (void)chain_launch<CK_LOWER_DOT>(st, dim3(Mp <= 64 ? 1 : 16), Lu, Q, M, Mp, out);
   LAUNCH_CHECK();
 }
 
 // WT[(d*Mp + j)*Mp + i] = Wcat[i*(D*Mp) + d*Mp + j]: the W_d^T stacked vertically ([D*Mp x Mp]), the B operand of
 // dC = [2 vbar .* T] * WTcat when t_d = W_d^T c is kept from the forward pass
-__global__ void wcat_transpose_kernel(const double* __restrict__ Wcat, int Mp, int D, double* __restrict__ WT) {
-  __shared__ double tile[32][33];
-  const int d = blockIdx.z;
-  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
-  for (int r = ty; r < 32; r += 8) tile[r][tx] = Wcat[(long)(i0 + r) * D * Mp + (long)d * Mp + j0 + tx];
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) WT[((long)d * Mp + j0 + r) * Mp + i0 + tx] = tile[tx][r];
-}
 hipError_t wcat_transpose(hipStream_t st, const double* Wcat, int Mp, int D, double* WT) {
-  hipLaunchKernelGGL(wcat_transpose_kernel, dim3(Mp / 32, Mp / 32, D), dim3(256), 0, st, Wcat, Mp, D, WT);
+  (void)chain_launch<CK_WCAT_T>(st, dim3(Mp / 32, Mp / 32, D), Wcat, Mp, D, WT);
   LAUNCH_CHECK();
 }
 
-__global__ void sub_identity_kernel(double* __restrict__ S, int M, int Mp, long total) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int i = (int)((idx / Mp) % Mp), j = (int)(idx % Mp);
-  if (i >= M || j >= M) S[idx] = 0.0;            // padding: W_pad = I so W W^T - I = 0 there
-  else if (i == j) S[idx] -= 1.0;
-}
 hipError_t sub_identity(hipStream_t st, double* S, int M, int Mp, int batch) {
   const long n = (long)batch * Mp * Mp;
-  hipLaunchKernelGGL(sub_identity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, M, Mp, n);
+  (void)chain_launch<CK_SUB_IDENTITY>(st, dim3((unsigned)((n + 255) / 256)), S, M, Mp, n);
   LAUNCH_CHECK();
 }
 
 // G (lower triangle valid) -> symmetric: tile (bi, bj) with bj > bi takes the transpose of tile (bj, bi) through LDS
 // (coalesced reads and writes; the element-wise version read G column-wise right after the atomics of the Gram product
 // had left it in HBM: 167 us for 8 x 256^2, on the critical path of the last layer's chain), diagonal tiles in place.
-__global__ __launch_bounds__(256) void symmetrize_lower_kernel(double* __restrict__ G, int Mp) {
-  __shared__ double tile[32][33];
-  const int nb = Mp / 32;
-  // enumerate the pairs bi <= bj
-  int t = blockIdx.x, bi = 0;
-  while (t >= nb - bi) { t -= nb - bi; ++bi; }
-  const int bj = bi + t;
-  double* __restrict__ Gb = G + (long)blockIdx.y * Mp * Mp;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
-  for (int r = ty; r < 32; r += 8) tile[r][tx] = Gb[(long)(bj * 32 + r) * Mp + bi * 32 + tx];     // lower tile (bj, bi)
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int i = bi * 32 + r, j = bj * 32 + tx;
-    if (j > i) Gb[(long)i * Mp + j] = tile[tx][r];
-  }
-}
 hipError_t symmetrize_lower(hipStream_t st, double* G, int Mp, int batch) {
   const int nb = Mp / 32;
-  hipLaunchKernelGGL(symmetrize_lower_kernel, dim3((unsigned)(nb * (nb + 1) / 2), (unsigned)batch), dim3(256), 0, st, G, Mp);
+  (void)chain_launch<CK_SYMMETRIZE>(st, dim3((unsigned)(nb * (nb + 1) / 2), (unsigned)batch), G, Mp);
   LAUNCH_CHECK();
 }
 
-__global__ void sub_scalars_kernel(const double* a, const double* b, double* out) { out[0] = a[0] - b[0]; }
 hipError_t sub_scalars(hipStream_t st, const double* a, const double* b, double* out) {
-  hipLaunchKernelGGL(sub_scalars_kernel, dim3(1), dim3(1), 0, st, a, b, out);
+  (void)chain_launch<CK_SUB_SCALARS>(st, dim3(1), a, b, out);
   LAUNCH_CHECK();
 }
 
@@ -430,160 +210,51 @@ __device__ __forceinline__ double block_sum_1024(double v, double* sh) {
   return t;    // valid on thread 0
 }
 
-__global__ __launch_bounds__(256) void layer_kl_kernel(const double* __restrict__ Wcat, const double* __restrict__ u,
-                                                       const double* __restrict__ Lq, const double* __restrict__ Lu,
-                                                       int M, int Mp, int D, int white, double* __restrict__ out) {
-  __shared__ double sh[4];
-  double acc = 0.0;
-  const long nW = (long)Mp * D * Mp, gstride = (long)gridDim.x * blockDim.x, g0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  for (long idx = g0; idx < nW; idx += gstride) {
-    const int k = (int)(idx / ((long)D * Mp)), n = (int)(idx % Mp);
-    if (k < M && n < M) { const double w = Wcat[idx]; acc += 0.5 * w * w; }
-  }
-  for (long idx = g0; idx < (long)M * D; idx += gstride) { const double x = u[idx]; acc += 0.5 * x * x; }
-  for (long idx = g0; idx < (long)D * M; idx += gstride) {
-    const int d = (int)(idx / M), i = (int)(idx % M);
-    const double q = Lq[((long)d * Mp + i) * Mp + i];
-    acc -= 0.5 * log(q * q);
-  }
-  if (!white)
-    for (long i = g0; i < M; i += gstride) acc += (double)D * log(Lu[i * Mp + i]);
-  if (g0 == 0) acc -= 0.5 * (double)D * (double)M;
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
-}
-
 hipError_t layer_kl(hipStream_t st, const double* Wcat, const double* u, const double* Lq, const double* Lu, int M,
                     int Mp, int D, int white, double* kl_out) {
-  hipLaunchKernelGGL(layer_kl_kernel, dim3(64), dim3(256), 0, st, Wcat, u, Lq, Lu, M, Mp, D, white, kl_out);
+  (void)chain_launch<CK_LAYER_KL>(st, dim3(Mp <= 64 ? 1 : 64), Wcat, u, Lq, Lu, M, Mp, D, white, kl_out);   // (grid-stride loops: one block covers a small layer)
   LAUNCH_CHECK();
 }
 
 // ---------------------------------------------------------------------------------------- backward chain pieces
-__global__ void wbar_total_kernel(double* __restrict__ dW, const double* __restrict__ W, double* __restrict__ du,
-                                  const double* __restrict__ u, int M, int Mp, int D) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long nW = (long)Mp * D * Mp;
-  if (idx < nW) {
-    const int k = (int)(idx / ((long)D * Mp)), n = (int)(idx % Mp);
-    dW[idx] = (k < M && n < M && n <= k) ? (dW[idx] - W[idx]) : 0.0;
-  }
-  if (idx < (long)Mp * D) {
-    const int i = (int)(idx / D);
-    du[idx] = (i < M) ? (du[idx] - u[idx]) : 0.0;
-  }
-}
 hipError_t wbar_total(hipStream_t st, double* dWcat, const double* Wcat, double* du, const double* u, int M, int Mp,
                       int D) {
   const long n = (long)Mp * D * Mp;
-  hipLaunchKernelGGL(wbar_total_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dWcat, Wcat, du, u, M, Mp,
-                     D);
+  (void)chain_launch<CK_WBAR_TOTAL>(st, dim3((unsigned)((n + 255) / 256)), dWcat, Wcat, du, u, M, Mp, D);
   LAUNCH_CHECK();
 }
 
-__global__ void lqbar_finish_kernel(double* __restrict__ dLq, const double* __restrict__ Lq, int M, int Mp, int D) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)D * Mp * Mp) return;
-  const int i = (int)((idx / Mp) % Mp), j = (int)(idx % Mp);
-  double v = 0.0;
-  if (i < M && j <= i) v = dLq[idx] + (i == j ? 1.0 / Lq[idx] : 0.0);
-  dLq[idx] = v;
-}
 hipError_t lqbar_finish(hipStream_t st, double* dLq, const double* Lq, int M, int Mp, int D) {
   const long n = (long)D * Mp * Mp;
-  hipLaunchKernelGGL(lqbar_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dLq, Lq, M, Mp, D);
+  (void)chain_launch<CK_LQBAR>(st, dim3((unsigned)((n + 255) / 256)), dLq, Lq, M, Mp, D);
   LAUNCH_CHECK();
 }
 
-__global__ void lubar_finish_kernel(double* __restrict__ dLu, const double* __restrict__ T2, const double* __restrict__ Lu,
-                                    int M, int Mp, int D, int white) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)Mp * Mp) return;
-  const int i = (int)(idx / Mp), j = (int)(idx % Mp);
-  double v = 0.0;
-  if (i < M && j <= i) {
-    v = -(dLu[idx] + (T2 ? T2[idx] : 0.0));
-    if (i == j && !white) v -= (double)D / Lu[idx];
-  }
-  dLu[idx] = v;
-}
 hipError_t lubar_finish(hipStream_t st, double* dLu, const double* T2, const double* Lu, int M, int Mp, int D,
                         int white) {
   const long n = (long)Mp * Mp;
-  hipLaunchKernelGGL(lubar_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dLu, T2, Lu, M, Mp, D,
-                     white);
+  (void)chain_launch<CK_LUBAR>(st, dim3((unsigned)((n + 255) / 256)), dLu, T2, Lu, M, Mp, D, white);
   LAUNCH_CHECK();
 }
 
-__global__ void phi_kernel(double* __restrict__ T, int Mp, long total) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int i = (int)((idx / Mp) % Mp), j = (int)(idx % Mp);
-  const double v = T[idx];
-  T[idx] = (j < i) ? v : (i == j ? 0.5 * v : 0.0);
-}
 hipError_t phi_tril_halfdiag(hipStream_t st, double* T, int Mp, int batch) {
   const long n = (long)batch * Mp * Mp;
-  hipLaunchKernelGGL(phi_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, T, Mp, n);
+  (void)chain_launch<CK_PHI>(st, dim3((unsigned)((n + 255) / 256)), T, Mp, n);
   LAUNCH_CHECK();
 }
 
 // RBF backward through Kuu = K(Z,Z) + jitter*I with dKuu = sym(S)   
-__global__ __launch_bounds__(64) void rbf_kuu_bwd_kernel(const double* __restrict__ S, const double* __restrict__ Kuu,
-                                                         const double* __restrict__ Euu,
-                                                         const double* __restrict__ Z, const double* __restrict__ var,
-                                                         const double* __restrict__ ls, int M, int Mp, int Din,
-                                                         double* __restrict__ dZ, double* __restrict__ dls,
-                                                         double* __restrict__ dvar, const double* __restrict__ white) {
-  // one wave per (inducing point m, input dimension j): lanes stride over n, so rows of Kuu and S are read coalesced
-  const int m = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
-  const double zm = Z[(long)m * Din + j], l = ls[j];
-  double zacc = 0.0, lacc = 0.0, vacc = 0.0;
-  for (int n = lane; n < M; n += 64) {
-    const double k0 = Kuu[(long)m * Mp + n] - (m == n ? kJitter + (white ? white[0] : 0.0) : 0.0);
-    const double sym = 0.5 * (S[(long)m * Mp + n] + S[(long)n * Mp + m]);
-    const double h = sym * (Euu ? Euu[(long)m * Mp + n] : k0);       // dKuu .* e: inputs and lengthscales
-    const double dl = zm - Z[(long)n * Din + j];
-    zacc += h * dl;
-    lacc += h * dl * dl;
-    vacc += sym * k0;                                                 // dKuu .* k: variance
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    zacc += __shfl_down(zacc, o);
-    lacc += __shfl_down(lacc, o);
-    vacc += __shfl_down(vacc, o);
-  }
-  if (lane == 0) {
-    dZ[(long)m * Din + j] += -2.0 * zacc / (l * l);
-    unsafeAtomicAdd(dls + j, lacc / (l * l * l));
-    if (j == 0) unsafeAtomicAdd(dvar, vacc / var[0]);
-  }
-}
 hipError_t rbf_kuu_bwd(hipStream_t st, const double* S, const double* Kuu, const double* Euu, const double* Z,
                        const double* var, const double* ls, int M, int Mp, int Din, double* dZ, double* dls, double* dvar,
                        const double* white) {
-  hipLaunchKernelGGL(rbf_kuu_bwd_kernel, dim3(M, Din), dim3(64), 0, st, S, Kuu, Euu, Z, var, ls, M, Mp, Din, dZ, dls, dvar,
-                     white);
+  (void)chain_launch<CK_KUU_BWD>(st, dim3(M, Din), S, Kuu, Euu, Z, var, ls, M, Mp, Din, dZ, dls, dvar, white);
   LAUNCH_CHECK();
 }
 
-__global__ void unpack_q_grads_kernel(const double* __restrict__ dLq, const double* __restrict__ dqmu_p, int M, int Mp,
-                                      int D, double* __restrict__ g_q_sqrt, double* __restrict__ g_q_mu) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < (long)D * M * M) {
-    const int d = (int)(idx / ((long)M * M));
-    const int i = (int)((idx / M) % M), j = (int)(idx % M);
-    g_q_sqrt[idx] = (j <= i) ? dLq[((long)d * Mp + i) * Mp + j] : 0.0;
-  }
-  if (idx < (long)M * D) g_q_mu[idx] = dqmu_p[idx];
-}
 hipError_t unpack_q_grads(hipStream_t st, const double* dLq, const double* dqmu_p, int M, int Mp, int D,
                           double* g_q_sqrt, double* g_q_mu) {
   const long n = (long)D * M * M;
-  hipLaunchKernelGGL(unpack_q_grads_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dLq, dqmu_p, M, Mp, D,
-                     g_q_sqrt, g_q_mu);
+  (void)chain_launch<CK_UNPACK_Q>(st, dim3((unsigned)((n + 255) / 256)), dLq, dqmu_p, M, Mp, D, g_q_sqrt, g_q_mu);
   LAUNCH_CHECK();
 }
 

@@ -1378,3 +1378,15 @@ def test_config2_shape_production_kernels_against_the_oracle(tmp_path):
     for k in (0, 2):
         assert abs(float(res[k]["elbo"]) - float(res[1]["elbo"])) < 1e-13 * abs(float(res[1]["elbo"]))
         np.testing.assert_allclose(res[k]["grad"], res[1]["grad"], rtol=0, atol=1e-12 * np.abs(res[1]["grad"]).max())
+
+
+def test_recorded_chains_give_the_launch_by_launch_results():
+    """DGP_CHAIN=1 (off by default: measured slower, NOTES.md): the per-layer small-matrix chains of an M <= 64 model are
+    recorded once and replayed by one workgroup in one launch (csrc/chain.h) - the same kernel bodies in the same order, so
+    the golden parity tests must pass unchanged.  The switch is read at context creation: child process."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "golden or notebook_known or two_adam or matern_two"], env=dict(os.environ, DGP_CHAIN="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:]
