@@ -91,6 +91,7 @@ struct dgp_ctx {
   double data_scale = 1.0;          // factor on the data term (N / batch size for a minibatch estimate)
   double *acc = nullptr, *acc_own = nullptr;
   double *gram_ws = nullptr;                         // partial triangles of the weighted Gram kernel (layers with Mp = 256)
+  double *sl_ws = nullptr;                           // per-block partial sums of the fused small-layer backward (small_layer.hip)
   long n_acc = 0;
   double* scal = nullptr;   // device scalars: [0] sum KL, [1] ELBO of last grad_finish, [2] scratch data term
   int* info = nullptr;
@@ -400,7 +401,7 @@ void free_model(dgp_ctx* ctx) {
   }
   ctx->L.clear();
   dev_free(ctx->params); dev_free(ctx->grad); dev_free(ctx->adam_m); dev_free(ctx->adam_v);
-  dev_free(ctx->segs_dev); dev_free(ctx->mean_params); dev_free(ctx->acc_own); dev_free(ctx->gram_ws);
+  dev_free(ctx->segs_dev); dev_free(ctx->mean_params); dev_free(ctx->acc_own); dev_free(ctx->gram_ws); dev_free(ctx->sl_ws);
   ctx->acc = nullptr;
   for (auto& set : ctx->smset) for (auto& s : set) dev_free(s);
   for (auto& z : ctx->zs_dev) dev_free(z);
@@ -745,6 +746,11 @@ GemmArgs args_g(long Pm, int Mp, const double* Cbar, const double* Linv, double*
   return a;
 }
 
+// a layer whose per-point work runs in the fused small-model kernels (forward AND backward: they share the row-major t_d)
+bool small_fused(const dgp_ctx* ctx, const Layer& y) {
+  return ctx->store_t && y.d.kernel_kind != DGP_KERNEL_MF && small_layer_ok(y.d.kernel_kind, y.Mp, y.d.D_out, y.d.D_in);
+}
+
 // mean (before the mean function) = Ct u, and its adjoint reduction over the points du += Ct^T mbar
 GemmArgs args_mean0(long Pm, int Mp, int D, const double* Ct, const double* u, double* mean0) {
   return mk(Pm, D, Mp, Ct, Mp, u, D, mean0, D);
@@ -792,17 +798,25 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
     // when it applies, else on the 128 x 64 engine (Mp/32 planes, the triangular solve as an NT product).
     GemmArgs aC = args_Ct(Pm, Mp, y.Kt, y.LinvT, y.Ct, y.cnp);
     GemmArgs aT = args_T(Pm, Mp, D, y.Ct, y.Wcat, y.Tt, y.tnp, ctx->blocked_t);
-    {
-      ProfScope ps(ctx, 1, 0, (double)Pl * (Mp + Din) * 8);
-      if (y.d.kernel_kind == DGP_KERNEL_MF)
-        HIPCHK(mf_kuf(ctx->st, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), M, Mp, Din, y.Kt));
-      else
-        HIPCHK(rbf_kuf(ctx->st, y.d.kernel_kind, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
-                       y.Kt, y.Et));
-    }
     int nplane = 0;
-    RET(launch_Ct_T(ctx, aC, aT, y.Linv, Pl, &nplane));
-    RET(GX(ctx, 0, GEMM_NN, args_mean0(Pm, Mp, D, y.Ct, y.u, y.mean0), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
+    if (small_fused(ctx, y)) {
+      // at most 64 inducing points: Kuf, c, t_d, mean0 and the row norms in ONE launch (small_layer.hip)
+      ProfScope ps(ctx, 0, (double)Pl * Mp * (Mp + 1.0) * (1 + D), (double)Pl * Mp * 8 * (2 + D));
+      HIPCHK(small_layer_fwd(ctx->st, y.d.kernel_kind, Xin, Pl, row0, Din, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, D,
+                             y.LinvT, y.Wcat, y.u, y.Kt, y.Et, y.Ct, y.Tt, y.cnp, y.tnp, Pm, y.mean0));
+      nplane = 1;
+    } else {
+      {
+        ProfScope ps(ctx, 1, 0, (double)Pl * (Mp + Din) * 8);
+        if (y.d.kernel_kind == DGP_KERNEL_MF)
+          HIPCHK(mf_kuf(ctx->st, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), M, Mp, Din, y.Kt));
+        else
+          HIPCHK(rbf_kuf(ctx->st, y.d.kernel_kind, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
+                         y.Kt, y.Et));
+      }
+      RET(launch_Ct_T(ctx, aC, aT, y.Linv, Pl, &nplane));
+      RET(GX(ctx, 0, GEMM_NN, args_mean0(Pm, Mp, D, y.Ct, y.u, y.mean0), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
+    }
     {
       ProfScope ps(ctx, 1, 0, (double)Pl * nplane * 8 * (1 + D));
       HIPCHK(finalize_layer(ctx->st, y.cnp, y.tnp, nplane, Pm, y.mean0, Xin, row0, Pl, Nc, S, dedup ? 1 : 0, Din, D,
@@ -840,6 +854,36 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     const long row0 = dedup ? n0 : 0;
     const long DM = (long)D * Mp, MM = (long)Mp * Mp;
     const double tri1 = (double)Pl * Mp * (Mp + 1.0);
+    if (small_fused(ctx, y) && y.Tt) {
+      // at most 64 inducing points: dC, g, g^T [Z | 1] and [X | 1] in one launch, the four sums over the points in a second
+      // (small_layer.hip); x-gradient and fold as for the large layers
+      const int w1 = Din + 1;
+      {
+        ProfScope ps(ctx, 0, tri1 * (1 + D), (double)Pl * Mp * 8 * (4 + D));
+        HIPCHK(small_layer_bwd(ctx->st, Xin, Pl, row0, Din, D, y.Linv, y.Scat, y.u, y.Z1, y.Ct, y.Tt, y.Et ? y.Et : y.Kt, y.vbar, y.mbar,
+                               ctx->Cbar, ctx->Gt, ctx->R1, ctx->X1));
+      }
+      if (o.params) {
+        ProfScope ps(ctx, 0, tri1 * (1 + D), (double)Pl * Mp * 8 * 3);
+        if (!ctx->sl_ws) RET(dev_alloc(ctx, &ctx->sl_ws, (size_t)small_layer_sums_ws_doubles()));
+        HIPCHK(small_layer_sums(ctx->st, Pl, Din, D, y.Ct, ctx->Cbar, ctx->Gt, y.vbar, y.mbar, ctx->X1, acc + y.acc_G, acc + y.acc_Q,
+                                acc + y.acc_du, acc + y.acc_GX, ctx->sl_ws));
+      }
+      {
+        ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 24);
+        HIPCHK(xbar_finish(ctx->st, ctx->R1, ctx->X1, Pl, P(ctx, y.off_ls), Din, D, y.d.mean_kind, y.meanW, y.mbar,
+                           (l > 0 || o.xgrad0) ? 1 : 0, ctx->xbar, o.params ? acc + y.acc_x2 : nullptr));
+      }
+      if (l > 0) {
+        Layer& w = ctx->L[l - 1];
+        ProfScope ps(ctx, 1, 0, (double)S * Nc * Din * 24);
+        HIPCHK(fold_sample_grad(ctx->st, ctx->xbar, w.var, Nc, S, (l - 1 == 0) ? 1 : 0, w.d.D_out,
+                                zsrc_of(ctx, l - 1, use_zs, seed, o.n_goff, o.Ntot), n0, w.mbar, w.vbar,
+                                o.params ? acc + w.acc_dvar : nullptr));
+      }
+      if (o.after_layer) RET(o.after_layer(ctx, l));
+      continue;
+    }
     if (y.Tt) {  // dC = sum_d 2 vbar_d (W_d t_d - c): [2 vbar .* T] * WTcat, W_d lower => k <= n per block; "- c" in the epilogue
       GemmArgs a = args_Cbar(Pm, Mp, D, y.Tt, y.Scat, ctx->Cbar, y.vbar, y.Ct, y.mbar, y.u, ctx->blocked_t);
       RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 8 * (2 + D)));

@@ -151,6 +151,21 @@ hipError_t vjp_seed(hipStream_t st, const double* fbar, const double* meanbar, c
                     long Nc, int S, int dedup, int D, ZSource zsrc, long Ntot, long n_chunk0, double* mbar, double* vbar,
                     double* acc_dkvar = nullptr);
 hipError_t cbar_fix(hipStream_t st, double* Cbar, const double* mbar, const double* u, long P, int Mp, int D);
+// fused per-point kernels of a layer with Mp = 64 (small_layer.hip): forward (Kuf, c, t_d, mean0, row norms), backward per
+// point (dC, g, g^T [Z | 1], [X | 1]) and the backward's sums over the points (G_d, Q', du, g^T [X | 1])
+bool small_layer_ok(int kind, int Mp, int D, int Din);
+hipError_t small_layer_fwd(hipStream_t st, int kind, const double* Xin, long P, long x_row0, int Din, const double* Z,
+                           const double* var, const double* ls, int M, int D, const double* LinvT, const double* Wcat,
+                           const double* u, double* Kt, double* Et, double* Ct, double* Tt, double* cn, double* tn,
+                           long pstride, double* mean0);
+hipError_t small_layer_bwd(hipStream_t st, const double* Xin, long P, long x_row0, int Din, int D, const double* Linv,
+                           const double* Scat, const double* u, const double* Z1, const double* Ct, const double* Tt,
+                           const double* Ek, const double* vbar, const double* mbar, double* Cbar, double* Gt, double* R1,
+                           double* X1);
+hipError_t small_layer_sums(hipStream_t st, long P, int Din, int D, const double* Ct, const double* Cbar, const double* Gt,
+                            const double* vbar, const double* mbar, const double* X1, double* accG, double* accQ, double* accdu,
+                            double* accGX, double* ws /* >= small_layer_sums_ws_doubles() */);
+long small_layer_sums_ws_doubles();
 hipError_t make_x1(hipStream_t st, const double* Xin, long x_row0, long P, int Din, double* X1);     // [X | 1]
 hipError_t xbar_finish(hipStream_t st, const double* R1, const double* X1, long P, const double* ls, int Din, int D,
                        int mean_kind, const double* meanW, const double* mbar, int want_xbar, double* xbar,

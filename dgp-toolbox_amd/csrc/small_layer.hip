@@ -1,0 +1,401 @@
+// Fused per-point kernels of an SVGP layer with at most 64 inducing points (Mp = 64): the Bayesian-optimisation surrogates
+// of SO_BO.py:248-258 (tens of inducing points, a few hundred to a few thousand points).  At that size the per-layer
+// sequence Kuf -> Ct -> T -> mean0 and its adjoint ran as 4 + 8 launches of the 128 x 64 MFMA engine at 11-35 us each (a
+// 1000-point product is a handful of tiles: the engine's pipeline never fills), i.e. 0.4 of the 0.67 ms of a config-1
+// training iteration.  Here: one wave per point, lane = inducing index, the layer's 64 x 64 matrices in LDS, matrix-vector
+// products as 64 broadcast-FMA steps (v_readlane + ds_read + v_fma); the reductions over the points as one launch.
+//
+// Reference arithmetic (whitened form, DESIGN.md par. 2):
+//   forward  (layers.py:243-276):  k = K(Z, x), c = Lu^-1 k, t_d = W_d^T c, mean0_d = c . u_d, |c|^2, |t_d|^2
+//   backward:      cb = sum_d mbar_d u_d + sum_d 2 vbar_d (W_d t_d - c),  kb = Lu^-T cb,  g = kb .* e,
+//                                  R1 = g^T [Z | 1];   sums over points: G_d, Q', du, g^T [X | 1]
+// Outputs have the layouts the unfused path uses (Kt, Ct, Cbar, Gt point-major [P][64]; T row-major [P][D * 64]; one
+// row-norm plane), so finalize_layer, xbar_finish, fold and the small-matrix chains run unchanged behind them.
+#include "dgp_internal.h"
+
+namespace dgp {
+
+namespace {
+
+constexpr int SL_M = 64;           // Mp
+constexpr int SL_MAXD = 3;         // outputs whose W_d fit the LDS beside Linv (32 KB each)
+
+__device__ __forceinline__ double sl_bcast(double v, int lane) {       // lane: wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sl_wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr int SL_Q = 4;            // points a wave works on at once: one LDS read of a matrix row serves SL_Q matrix-vector products,
+                                   // SL_Q independent accumulation chains hide the FMA and LDS latencies (1 wave per SIMD)
+
+// y_q[lane] = sum_j A[j][lane] * x_q[j], q < SL_Q.  A: LDS image [64][64] (row j contiguous over the lanes); x: the wave's
+// LDS scratch xs[q][64] (written by the wave itself: a uniform address is a broadcast read)
+__device__ __forceinline__ void sl_matvec4(const double* __restrict__ A, const double* __restrict__ xs, double (&y)[SL_Q]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < SL_Q; ++q) y[q] = 0.0;
+#pragma unroll 8
+  for (int j = 0; j < SL_M; ++j) {
+    const double a = A[j * SL_M + lane];
+#pragma unroll
+    for (int q = 0; q < SL_Q; ++q) y[q] = fma(a, xs[q * SL_M + j], y[q]);
+  }
+}
+__device__ __forceinline__ void sl_wave_fence() {        // the wave's own LDS writes are visible to its later reads
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void sl_wave_sum4(double (&v)[SL_Q]) {
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int q = 0; q < SL_Q; ++q) v[q] += __shfl_xor(v[q], o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- forward
+// grid: blocks of 4 waves; a wave takes the block's points in groups of SL_Q
+__global__ __launch_bounds__(256) void small_layer_fwd_kernel(
+    int kind, const double* __restrict__ Xin, long P, long x_row0, int Din, const double* __restrict__ Z, const double* __restrict__ var,
+    const double* __restrict__ ls, int M, int D, const double* __restrict__ LinvT, const double* __restrict__ Wcat,
+    const double* __restrict__ u, double* __restrict__ Kt, double* __restrict__ Et, double* __restrict__ Ct, double* __restrict__ Tt,
+    double* __restrict__ cn, double* __restrict__ tn, long pstride, double* __restrict__ mean0, int pts_per_block) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sL = smem;                           // LinvT [64][64]:  c[m] = sum_j LinvT[j][m] k[j]
+  double* sW = smem + SL_M * SL_M;             // W_d [m][n] (d-major):  t_d[n] = sum_m W_d[m][n] c[m]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* xs = smem + (1 + D) * SL_M * SL_M + wave * SL_Q * SL_M;      // the wave's vectors
+  for (int i = tid; i < SL_M * SL_M; i += 256) sL[i] = LinvT[i];
+  for (int i = tid; i < D * SL_M * SL_M; i += 256) {
+    const int d = i / (SL_M * SL_M), r = i % (SL_M * SL_M), m = r / SL_M, n = r % SL_M;
+    sW[i] = Wcat[(long)m * D * SL_M + (long)d * SL_M + n];
+  }
+  __syncthreads();
+  const double v0 = var[0];
+  double ud[SL_MAXD];
+#pragma unroll
+  for (int d = 0; d < SL_MAXD; ++d) ud[d] = d < D ? u[(long)lane * D + d] : 0.0;
+  const long p0 = (long)blockIdx.x * pts_per_block, p1 = min(P, p0 + pts_per_block);
+  for (long pg = p0 + wave * SL_Q; pg < p1; pg += 4 * SL_Q) {
+    double k[SL_Q], c[SL_Q], t[SL_Q], red[SL_Q];
+#pragma unroll
+    for (int q = 0; q < SL_Q; ++q) {
+      const long p = min(pg + q, p1 - 1);            // (a short last group repeats its last point; only p < p1 is stored)
+      const double* __restrict__ x = Xin + (x_row0 + p) * Din;
+      double r2 = 0.0, e = 0.0;
+      k[q] = 0.0;
+      if (lane < M) {
+        for (int j = 0; j < Din; ++j) { const double dd = (x[j] - Z[(long)lane * Din + j]) / ls[j]; r2 += dd * dd; }
+        stationary_k(kind, v0, r2, k[q], e);
+      }
+      if (pg + q < p1) {
+        Kt[p * SL_M + lane] = k[q];
+        if (Et) Et[p * SL_M + lane] = e;
+      }
+      xs[q * SL_M + lane] = k[q];
+    }
+    sl_wave_fence();
+    sl_matvec4(sL, xs, c);
+    sl_wave_fence();
+#pragma unroll
+    for (int q = 0; q < SL_Q; ++q) {
+      if (pg + q < p1) Ct[(pg + q) * SL_M + lane] = c[q];
+      xs[q * SL_M + lane] = c[q];
+      red[q] = c[q] * c[q];
+    }
+    sl_wave_sum4(red);
+    if (lane < SL_Q && pg + lane < p1) cn[pg + lane] = lane == 0 ? red[0] : (lane == 1 ? red[1] : (lane == 2 ? red[2] : red[3]));
+    sl_wave_fence();
+    for (int d = 0; d < D; ++d) {
+      sl_matvec4(sW + d * SL_M * SL_M, xs, t);
+      const double udd = d == 0 ? ud[0] : (d == 1 ? ud[1] : ud[2]);
+      double m0[SL_Q];
+#pragma unroll
+      for (int q = 0; q < SL_Q; ++q) {
+        if (Tt && pg + q < p1) Tt[(pg + q) * (long)D * SL_M + (long)d * SL_M + lane] = t[q];
+        red[q] = t[q] * t[q];
+        m0[q] = c[q] * udd;
+      }
+      sl_wave_sum4(red);
+      sl_wave_sum4(m0);
+      if (lane < SL_Q && pg + lane < p1) {
+        const double tv = lane == 0 ? red[0] : (lane == 1 ? red[1] : (lane == 2 ? red[2] : red[3]));
+        const double mv = lane == 0 ? m0[0] : (lane == 1 ? m0[1] : (lane == 2 ? m0[2] : m0[3]));
+        tn[(long)d * pstride + pg + lane] = tv;
+        mean0[(pg + lane) * D + d] = mv;
+      }
+    }
+    sl_wave_fence();                                  // (the next group overwrites xs)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- backward, per point
+__global__ __launch_bounds__(256) void small_layer_bwd_kernel(
+    const double* __restrict__ Xin, long P, long x_row0, int Din, int D, const double* __restrict__ Linv, const double* __restrict__ Scat,
+    const double* __restrict__ u, const double* __restrict__ Z1, const double* __restrict__ Ct, const double* __restrict__ Tt,
+    const double* __restrict__ Ek, const double* __restrict__ vbar, const double* __restrict__ mbar, double* __restrict__ Cbar,
+    double* __restrict__ Gt, double* __restrict__ R1, double* __restrict__ X1, int pts_per_block) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sL = smem;                           // Linv [j][m]:     kb[m] = sum_j Linv[j][m] cb[j]
+  double* sS = smem + SL_M * SL_M;             // W_d^T [n][m]:    (W_d t_d)[m] = sum_n W_d[m][n] t_d[n]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* xs = smem + (1 + D) * SL_M * SL_M + wave * SL_Q * SL_M;
+  const int w1 = Din + 1;
+  for (int i = tid; i < SL_M * SL_M; i += 256) sL[i] = Linv[i];
+  for (int i = tid; i < D * SL_M * SL_M; i += 256) sS[i] = Scat[i];
+  __syncthreads();
+  double ud[SL_MAXD];
+#pragma unroll
+  for (int d = 0; d < SL_MAXD; ++d) ud[d] = d < D ? u[(long)lane * D + d] : 0.0;
+  const long p0 = (long)blockIdx.x * pts_per_block, p1 = min(P, p0 + pts_per_block);
+  for (long pg = p0 + wave * SL_Q; pg < p1; pg += 4 * SL_Q) {
+    double cb[SL_Q], vs[SL_Q], wt[SL_Q], g[SL_Q];
+    long pq[SL_Q];
+#pragma unroll
+    for (int q = 0; q < SL_Q; ++q) { pq[q] = min(pg + q, p1 - 1); cb[q] = 0.0; vs[q] = 0.0; }
+    for (int d = 0; d < D; ++d) {
+      const double udd = d == 0 ? ud[0] : (d == 1 ? ud[1] : ud[2]);
+#pragma unroll
+      for (int q = 0; q < SL_Q; ++q) xs[q * SL_M + lane] = Tt[pq[q] * (long)D * SL_M + (long)d * SL_M + lane];
+      sl_wave_fence();
+      sl_matvec4(sS + d * SL_M * SL_M, xs, wt);
+      sl_wave_fence();
+#pragma unroll
+      for (int q = 0; q < SL_Q; ++q) {
+        const double vb = vbar[pq[q] * D + d], mb = mbar[pq[q] * D + d];
+        cb[q] += mb * udd + 2.0 * vb * wt[q];
+        vs[q] += vb;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < SL_Q; ++q) {
+      cb[q] -= 2.0 * vs[q] * Ct[pq[q] * SL_M + lane];
+      if (pg + q < p1) Cbar[pq[q] * SL_M + lane] = cb[q];
+      xs[q * SL_M + lane] = cb[q];
+    }
+    sl_wave_fence();
+    sl_matvec4(sL, xs, g);
+    sl_wave_fence();
+#pragma unroll
+    for (int q = 0; q < SL_Q; ++q) {
+      g[q] *= Ek[pq[q] * SL_M + lane];
+      if (pg + q < p1) Gt[pq[q] * SL_M + lane] = g[q];
+    }
+    for (int j = 0; j < w1; ++j) {
+      const double z1 = Z1[(long)lane * w1 + j];
+      double r[SL_Q];
+#pragma unroll
+      for (int q = 0; q < SL_Q; ++q) r[q] = g[q] * z1;
+      sl_wave_sum4(r);
+      if (lane < SL_Q && pg + lane < p1) {
+        const long p = pg + lane;
+        R1[p * w1 + j] = lane == 0 ? r[0] : (lane == 1 ? r[1] : (lane == 2 ? r[2] : r[3]));
+        X1[p * w1 + j] = j < Din ? Xin[(x_row0 + p) * Din + j] : 1.0;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- backward, sums over points
+// G_d += sum_p vbar_pd c_p c_p^T,  Q' += sum_p cb_p c_p^T,  du += sum_p c_p mbar_p^T,  GX += sum_p g_p [x_p | 1]^T.
+// A block takes `pts_per_block` points in tiles of 64 staged in LDS; thread (ty, tx) owns the 4 x 4 block (4 ty.., 4 tx..) of
+// every 64 x 64 output; the small outputs are spread over the threads; everything meets in fp64 atomics.
+__global__ __launch_bounds__(256) void small_layer_sums_kernel(
+    long P, int Din, int D, const double* __restrict__ Ct, const double* __restrict__ Cbar, const double* __restrict__ Gt,
+    const double* __restrict__ vbar, const double* __restrict__ mbar, const double* __restrict__ X1, double* __restrict__ ws,
+    long ws_stride, int pts_per_block) {
+  __shared__ __attribute__((aligned(16))) double smem[3 * 64 * SL_M + 2 * 64 * SL_MAXD + 64 * 33];
+  double* sC = smem;                       // [64 points][64]
+  double* sB = sC + 64 * SL_M;             // Cbar
+  double* sG = sB + 64 * SL_M;             // Gt
+  double* sV = sG + 64 * SL_M;             // vbar [64][D]
+  double* sM = sV + 64 * SL_MAXD;          // mbar [64][D]
+  double* sX = sM + 64 * SL_MAXD;          // X1 [64][w1]
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int w1 = Din + 1;
+  double aG[SL_MAXD][4][4], aQ[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      aQ[i][j] = 0.0;
+#pragma unroll
+      for (int d = 0; d < SL_MAXD; ++d) aG[d][i][j] = 0.0;
+    }
+  // small outputs: du [64][D] and GX [64][w1]: output o = tid, tid + 256, ... of the concatenated list
+  const int n_small = SL_M * (D + w1);
+  double aS[9];                            // ceil(64 * (3 + 33) / 256) = 9
+#pragma unroll
+  for (int q = 0; q < 9; ++q) aS[q] = 0.0;
+  const long p0 = (long)blockIdx.x * pts_per_block, p1 = min(P, p0 + pts_per_block);
+  for (long pt = p0; pt < p1; pt += 64) {
+    const int np = (int)min((long)64, p1 - pt);
+    __syncthreads();
+    for (int i = tid; i < 64 * SL_M; i += 256) {
+      const int r = i >> 6;
+      const bool ok = r < np;
+      sC[i] = ok ? Ct[pt * SL_M + i] : 0.0;
+      sB[i] = ok ? Cbar[pt * SL_M + i] : 0.0;
+      sG[i] = ok ? Gt[pt * SL_M + i] : 0.0;
+    }
+    for (int i = tid; i < 64 * D; i += 256) {
+      const int r = i / D, d = i - r * D;
+      const bool ok = r < np;
+      sV[r * SL_MAXD + d] = ok ? vbar[pt * D + i] : 0.0;
+      sM[r * SL_MAXD + d] = ok ? mbar[pt * D + i] : 0.0;
+    }
+    for (int i = tid; i < 64 * w1; i += 256) sX[i] = (i / w1) < np ? X1[pt * w1 + i] : 0.0;
+    __syncthreads();
+    for (int p = 0; p < np; ++p) {
+      double ci[4], cj[4], bi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ci[i] = sC[p * SL_M + 4 * ty + i]; cj[i] = sC[p * SL_M + 4 * tx + i]; bi[i] = sB[p * SL_M + 4 * ty + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aQ[i][j] = fma(bi[i], cj[j], aQ[i][j]);
+#pragma unroll
+      for (int d = 0; d < SL_MAXD; ++d) {
+        if (d < D) {
+          const double v = sV[p * SL_MAXD + d];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const double vc = v * ci[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) aG[d][i][j] = fma(vc, cj[j], aG[d][i][j]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int o = tid + 256 * q;
+      if (o < n_small) {
+        const int m = o & 63, col = o >> 6;           // col < D: du column; else GX column col - D
+        double a = 0.0;
+        if (col < D) { for (int p = 0; p < np; ++p) a = fma(sC[p * SL_M + m], sM[p * SL_MAXD + col], a); }
+        else { const int j = col - D; for (int p = 0; p < np; ++p) a = fma(sG[p * SL_M + m], sX[p * w1 + j], a); }
+        aS[q] += a;
+      }
+    }
+  }
+  // this block's partial sums, one slab per block: [D][64][64] G, [64][64] Q', [64][D] du, [64][w1] GX (no atomics: with every
+  // block adding to the same 8-20 thousand addresses the atomic adds were two thirds of the kernel's time)
+  double* __restrict__ out = ws + (long)blockIdx.x * ws_stride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 4 * ty + i;
+#pragma unroll
+    for (int d = 0; d < SL_MAXD; ++d)
+      if (d < D) {
+        const d4_t v = {aG[d][i][0], aG[d][i][1], aG[d][i][2], aG[d][i][3]};
+        *reinterpret_cast<d4_t*>(out + (long)d * SL_M * SL_M + r * SL_M + 4 * tx) = v;
+      }
+    const d4_t v = {aQ[i][0], aQ[i][1], aQ[i][2], aQ[i][3]};
+    *reinterpret_cast<d4_t*>(out + (long)D * SL_M * SL_M + r * SL_M + 4 * tx) = v;
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int o = tid + 256 * q;
+    if (o < n_small) {
+      const int m = o & 63, col = o >> 6;
+      const long base = (long)(D + 1) * SL_M * SL_M;
+      if (col < D) out[base + (long)m * D + col] = aS[q];
+      else out[base + (long)SL_M * D + (long)m * w1 + (col - D)] = aS[q];
+    }
+  }
+}
+
+// acc += sum over the blocks' slabs: one thread per output value, the blocks in a fixed order
+__global__ __launch_bounds__(256) void small_layer_sums_reduce_kernel(const double* __restrict__ ws, long ws_stride, int nblocks, int Din, int D,
+                                                                      double* __restrict__ accG, double* __restrict__ accQ,
+                                                                      double* __restrict__ accdu, double* __restrict__ accGX) {
+  const int w1 = Din + 1;
+  const long nG = (long)D * SL_M * SL_M, nQ = (long)SL_M * SL_M, ndu = (long)SL_M * D, nGX = (long)SL_M * w1;
+  const long o = (long)blockIdx.x * 256 + threadIdx.x;
+  if (o >= nG + nQ + ndu + nGX) return;
+  double s0 = 0.0, s1 = 0.0;
+  int b = 0;
+  for (; b + 2 <= nblocks; b += 2) { s0 += ws[(long)b * ws_stride + o]; s1 += ws[(long)(b + 1) * ws_stride + o]; }
+  if (b < nblocks) s0 += ws[(long)b * ws_stride + o];
+  const double v = s0 + s1;
+  if (o < nG) accG[o] += v;
+  else if (o < nG + nQ) accQ[o - nG] += v;
+  else if (o < nG + nQ + ndu) accdu[o - nG - nQ] += v;
+  else accGX[o - nG - nQ - ndu] += v;
+}
+
+int pts_per_block_for(long P) {
+  // a block's staging of the layer's matrices (64-128 KB from L2) is amortised over its points; 4 waves x SL_Q points per
+  // pass: at least one pass, at most ~2 blocks per CU over the whole launch
+  long ppb = 4 * SL_Q;
+  while (ppb < 4096 && (P + ppb - 1) / ppb > 512) ppb += 4 * SL_Q;
+  return (int)ppb;
+}
+
+}  // namespace
+
+bool small_layer_ok(int kind, int Mp, int D, int Din) {
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("DGP_SMALL_FUSED"); enabled = e ? atoi(e) : 1; }
+  return enabled && kind >= 0 && kind <= 2 && Mp == SL_M && D >= 1 && D <= SL_MAXD && Din >= 1 && Din <= 32;
+}
+
+// LDS of the per-point kernels: the layer's (1 + D) matrices + the waves' vectors; above 64 KB the kernel's limit is raised
+// once (hipFuncSetAttribute)
+static size_t sl_point_lds(int D) { return (size_t)((1 + D) * SL_M * SL_M + 4 * SL_Q * SL_M) * 8; }
+static void sl_raise_lds_limit() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_layer_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl_point_lds(SL_MAXD));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_layer_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl_point_lds(SL_MAXD));
+}
+
+hipError_t small_layer_fwd(hipStream_t st, int kind, const double* Xin, long P, long x_row0, int Din, const double* Z,
+                           const double* var, const double* ls, int M, int D, const double* LinvT, const double* Wcat,
+                           const double* u, double* Kt, double* Et, double* Ct, double* Tt, double* cn, double* tn,
+                           long pstride, double* mean0) {
+  if (P <= 0) return hipSuccess;
+  sl_raise_lds_limit();
+  const int ppb = pts_per_block_for(P);
+  hipLaunchKernelGGL(small_layer_fwd_kernel, dim3((unsigned)((P + ppb - 1) / ppb)), dim3(256), sl_point_lds(D), st, kind, Xin, P, x_row0, Din, Z,
+                     var, ls, M, D, LinvT, Wcat, u, Kt, Et, Ct, Tt, cn, tn, pstride, mean0, ppb);
+  return hipGetLastError();
+}
+
+hipError_t small_layer_bwd(hipStream_t st, const double* Xin, long P, long x_row0, int Din, int D, const double* Linv,
+                           const double* Scat, const double* u, const double* Z1, const double* Ct, const double* Tt,
+                           const double* Ek, const double* vbar, const double* mbar, double* Cbar, double* Gt, double* R1,
+                           double* X1) {
+  if (P <= 0) return hipSuccess;
+  sl_raise_lds_limit();
+  const int ppb = pts_per_block_for(P);
+  hipLaunchKernelGGL(small_layer_bwd_kernel, dim3((unsigned)((P + ppb - 1) / ppb)), dim3(256), sl_point_lds(D), st, Xin, P, x_row0, Din, D, Linv,
+                     Scat, u, Z1, Ct, Tt, Ek, vbar, mbar, Cbar, Gt, R1, X1, ppb);
+  return hipGetLastError();
+}
+
+long small_layer_sums_ws_doubles() { return 256L * ((SL_MAXD + 1L) * SL_M * SL_M + SL_M * (SL_MAXD + 33L)); }
+
+hipError_t small_layer_sums(hipStream_t st, long P, int Din, int D, const double* Ct, const double* Cbar, const double* Gt,
+                            const double* vbar, const double* mbar, const double* X1, double* accG, double* accQ, double* accdu,
+                            double* accGX, double* ws) {
+  if (P <= 0) return hipSuccess;
+  // tiles of 64 points, at most 256 blocks (the scratch holds 256 slabs)
+  long ppb = 64;
+  while ((P + ppb - 1) / ppb > 256) ppb += 64;
+  const int nblocks = (int)((P + ppb - 1) / ppb);
+  const long stride = (long)(D + 1) * SL_M * SL_M + (long)SL_M * (D + Din + 1);
+  hipLaunchKernelGGL(small_layer_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, P, Din, D, Ct, Cbar, Gt, vbar, mbar, X1, ws,
+                     stride, (int)ppb);
+  hipLaunchKernelGGL(small_layer_sums_reduce_kernel, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, ws, stride, nblocks, Din, D,
+                     accG, accQ, accdu, accGX);
+  return hipGetLastError();
+}
+
+}  // namespace dgp
