@@ -736,20 +736,23 @@ namespace {
 // backward_chunk hook (last chunk only): layer l's sums are final -> all-reduce its slice on the COMM stream (every
 // collective of the communicator is enqueued on that one stream, in the same order on every rank), then the layer's
 // small-matrix chain on one of the two chain streams, while the main stream runs the backward pass of the layers below
-int after_layer_hook(dgp_ctx* ctx, int l) {
+int after_layer_hook(dgp_ctx* ctx, int l, int phase) {
   const int nl = (int)ctx->L.size();
   Layer& y = ctx->L[l];
   const long lo = y.acc_Q, hi = (l + 1 < nl) ? ctx->L[l + 1].acc_Q : ctx->n_acc;     // the layer's contiguous slice
   const bool comm = ctx->nccl_comm != nullptr;
   const bool side = ctx->use_side && ctx->events_ok && nl <= dgp_ctx::kMaxEv;
   hipStream_t main_st = ctx->st;
+  if (phase == 0) {                             // layer l's sums are final behind this point of the main stream
+    if (side) HIPCHK(hipEventRecord(ctx->ev_layer[l], main_st));
+    return DGP_OK;
+  }
   hipStream_t chain_st = main_st, comm_st = main_st;
   int w = 0;
   if (side) {
     w = 1 + ((nl - 1 - l) % 2);                 // alternate the two chain streams, top layer first
     chain_st = ctx->side[w - 1];
     comm_st = ctx->side[dgp_ctx::kSide - 1];
-    HIPCHK(hipEventRecord(ctx->ev_layer[l], main_st));
     ctx->side_touched[w - 1] = true;
   }
   if (comm) {
@@ -775,7 +778,6 @@ int after_layer_hook(dgp_ctx* ctx, int l) {
   ctx->sm = ctx->smset[0];
   return r;
 }
-
 }  // namespace
 
 int dgp_grad_step(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs, double* elbo_out) {
@@ -810,7 +812,7 @@ int dgp_grad_step(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* z
     }
     RET(prep_flush(ctx));   // (no-op unless no chunk ran: the upper layers' prep chains are still owed)
     if (!hooked) {          // no data points on this rank: the chains still have to run (KL part), after the all-reduces
-      for (int l = nl - 1; l >= 0; --l) RET(after_layer_hook(ctx, l));
+      for (int l = nl - 1; l >= 0; --l) { RET(after_layer_hook(ctx, l, 0)); RET(after_layer_hook(ctx, l, 1)); }
     }
   }   // side streams joined
   RET(finish_tail(ctx));

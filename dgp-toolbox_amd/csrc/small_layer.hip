@@ -318,11 +318,19 @@ __global__ __launch_bounds__(256) void small_layer_sums_reduce_kernel(const doub
   const long nG = (long)D * SL_M * SL_M, nQ = (long)SL_M * SL_M, ndu = (long)SL_M * D, nGX = (long)SL_M * w1;
   const long o = (long)blockIdx.x * 256 + threadIdx.x;
   if (o >= nG + nQ + ndu + nGX) return;
-  double s0 = 0.0, s1 = 0.0;
+  double sa[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sa[i] = 0.0;
   int b = 0;
-  for (; b + 2 <= nblocks; b += 2) { s0 += ws[(long)b * ws_stride + o]; s1 += ws[(long)(b + 1) * ws_stride + o]; }
-  if (b < nblocks) s0 += ws[(long)b * ws_stride + o];
-  const double v = s0 + s1;
+  for (; b + 8 <= nblocks; b += 8) {                 // eight independent loads in flight, fixed association
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = ws[(long)(b + i) * ws_stride + o];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sa[i] += x[i];
+  }
+  for (; b < nblocks; ++b) sa[0] += ws[(long)b * ws_stride + o];
+  const double v = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
   if (o < nG) accG[o] += v;
   else if (o < nG + nQ) accQ[o - nG] += v;
   else if (o < nG + nQ + ndu) accdu[o - nG - nQ] += v;
