@@ -139,8 +139,24 @@ def main():
     ctx.adam_reset()
     flags = model._trainable_flags()
 
+    # single-process rehearsals of what a rank of a multi-GPU run executes (tools/shard_sizes.sh):
+    #   DGP_BENCH_PATH=partial  the three-stage form of the default collective (grad_partial -> [all-reduce] -> grad_finish)
+    #   DGP_BENCH_ONE_RANK_COMM=1  a one-rank library-owned RCCL communicator attached (DGP_COMM=native's path: per-layer
+    #                              all-reduce on the comm stream, persistent kernels leave 8 CUs free)
+    bench_path = os.environ.get("DGP_BENCH_PATH", "step")
+    if world == 1 and os.environ.get("DGP_BENCH_ONE_RANK_COMM") == "1":
+        from dgp_dace._native import Context
+        ctx.comm_init(0, 1, Context.comm_unique_id())
+
     def step():
-        c = model._grad_step(model.data)
+        if world == 1 and bench_path == "partial":
+            model._sync_data(model.data)
+            model._select_batch(ctx, True)
+            ctx.grad_partial(model.num_samples, model._next_seed(), None)
+            ctx.grad_finish()
+            c = ctx
+        else:
+            c = model._grad_step(model.data)
         c.adam_step(0.01, 0.9, 0.999, 1e-7, flags)
 
     def fence():
@@ -182,7 +198,7 @@ def main():
         # HBM bytes per launch of the dominant kernel family: NOT measured in this run (PMC counters need rocprofv3 passes
         # of their own); taken from the committed summary of those passes, whose commit / command travel with the number
         traffic, traffic_source = None, None
-        tpath = os.environ.get("DGP_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+        tpath = os.environ.get("DGP_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
         if world == 1 and os.path.exists(tpath) and (args.N, args.M, args.S) == (100_000, 256, 10):
             try:
                 tj = json.load(open(tpath))
