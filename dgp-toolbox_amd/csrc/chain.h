@@ -83,19 +83,46 @@ __device__ __forceinline__ T chain_get(const ChainSlot& s) {
   else return (T)s.l;
 }
 
+// kernel tags: they only give the stand-alone kernels readable names in profiles (chain_global<dgp::pack_q_kernel, ...>)
+struct rbf_kuu_kernel { static constexpr int id = CK_RBF_KUU; };
+struct leaf_potrf_inv_32_kernel { static constexpr int id = CK_LEAF32; };
+struct leaf_potrf_inv_64_kernel { static constexpr int id = CK_LEAF64; };
+struct copy_block_kernel { static constexpr int id = CK_COPY_BLOCK; };
+struct zero_block_kernel { static constexpr int id = CK_ZERO_BLOCK; };
+struct pack_q_kernel { static constexpr int id = CK_PACK_Q; };
+struct lq_to_wcat_kernel { static constexpr int id = CK_LQ_TO_WCAT; };
+struct copy_kernel { static constexpr int id = CK_COPY; };
+struct make_z1_kernel { static constexpr int id = CK_MAKE_Z1; };
+struct rbf_kuf_bwd_finish_kernel { static constexpr int id = CK_KUF_BWD_FINISH; };
+struct lower_dot_kernel { static constexpr int id = CK_LOWER_DOT; };
+struct wcat_transpose_kernel { static constexpr int id = CK_WCAT_T; };
+struct sub_identity_kernel { static constexpr int id = CK_SUB_IDENTITY; };
+struct symmetrize_lower_kernel { static constexpr int id = CK_SYMMETRIZE; };
+struct sub_scalars_kernel { static constexpr int id = CK_SUB_SCALARS; };
+struct layer_kl_kernel { static constexpr int id = CK_LAYER_KL; };
+struct wbar_total_kernel { static constexpr int id = CK_WBAR_TOTAL; };
+struct lqbar_finish_kernel { static constexpr int id = CK_LQBAR; };
+struct lubar_finish_kernel { static constexpr int id = CK_LUBAR; };
+struct phi_tril_halfdiag_kernel { static constexpr int id = CK_PHI; };
+struct rbf_kuu_bwd_kernel { static constexpr int id = CK_KUU_BWD; };
+struct unpack_q_grads_kernel { static constexpr int id = CK_UNPACK_Q; };
+struct zero_doubles_kernel { static constexpr int id = CK_ZERO1; };
+struct copy_2d_kernel { static constexpr int id = CK_COPY2D; };
+
 // ChainBody<KID>: kBlock (threads of the stand-alone kernel) and  template <int MODE> static void run(blockIdx, gridDim,
 // threadIdx, blockDim, args...)  - defined in chain_bodies.h
 template <int KID> struct ChainBody;
 
-template <int KID, typename... A>
-__global__ void __launch_bounds__(ChainBody<KID>::kBlock) chain_global(A... a) {
-  ChainBody<KID>::template run<CM_KERNEL>(VIdx{blockIdx.x, blockIdx.y, blockIdx.z}, VIdx{gridDim.x, gridDim.y, gridDim.z},
+template <typename TAG, typename... A>
+__global__ void __launch_bounds__(ChainBody<TAG::id>::kBlock) chain_global(A... a) {
+  ChainBody<TAG::id>::template run<CM_KERNEL>(VIdx{blockIdx.x, blockIdx.y, blockIdx.z}, VIdx{gridDim.x, gridDim.y, gridDim.z},
                                           VIdx{threadIdx.x, 0u, 0u}, VIdx{blockDim.x, 1u, 1u}, a...);
 }
 
 // launch the kernel KID now, or append it to the calling thread's recording
-template <int KID, typename... A>
+template <typename TAG, typename... A>
 inline hipError_t chain_launch(hipStream_t st, dim3 grid, A... a) {
+  constexpr int KID = TAG::id;
   static_assert(sizeof...(A) <= kChainSlots, "too many arguments for a chain op");
   if (ChainRec* r = chain_recorder()) {
     ChainOp op;
@@ -106,7 +133,7 @@ inline hipError_t chain_launch(hipStream_t st, dim3 grid, A... a) {
     r->ops.push_back(op);
     return hipSuccess;
   }
-  hipLaunchKernelGGL((chain_global<KID, A...>), grid, dim3(ChainBody<KID>::kBlock), 0, st, a...);
+  hipLaunchKernelGGL((chain_global<TAG, A...>), grid, dim3(ChainBody<KID>::kBlock), 0, st, a...);
   return hipGetLastError();
 }
 

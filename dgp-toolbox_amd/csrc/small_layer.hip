@@ -15,8 +15,6 @@
 
 namespace dgp {
 
-namespace {
-
 constexpr int SL_M = 64;           // Mp
 constexpr int SL_MAXD = 3;         // outputs whose W_d fit the LDS beside Linv (32 KB each)
 
@@ -337,15 +335,13 @@ __global__ __launch_bounds__(256) void small_layer_sums_reduce_kernel(const doub
   else accGX[o - nG - nQ - ndu] += v;
 }
 
-int pts_per_block_for(long P) {
+static int pts_per_block_for(long P) {
   // a block's staging of the layer's matrices (64-128 KB from L2) is amortised over its points; 4 waves x SL_Q points per
   // pass: at least one pass, at most ~2 blocks per CU over the whole launch
   long ppb = 4 * SL_Q;
   while (ppb < 4096 && (P + ppb - 1) / ppb > 512) ppb += 4 * SL_Q;
   return (int)ppb;
 }
-
-}  // namespace
 
 bool small_layer_ok(int kind, int Mp, int D, int Din) {
   static int enabled = -1;

@@ -13,7 +13,7 @@ namespace dgp {
 hipError_t rbf_kuu(hipStream_t st, int kind, const double* Z, const double* var, const double* ls, int M, int Mp, int Din,
                    double* Kuu, double* Euu) {
   const long n = (long)Mp * Mp;
-  (void)chain_launch<CK_RBF_KUU>(st, dim3((unsigned)((n + 255) / 256)), kind, Z, var, ls, M, Mp, Din, Kuu, Euu);
+  (void)chain_launch<rbf_kuu_kernel>(st, dim3((unsigned)((n + 255) / 256)), kind, Z, var, ls, M, Mp, Din, Kuu, Euu);
   LAUNCH_CHECK();
 }
 
@@ -52,7 +52,7 @@ static hipError_t potrf_inv_rec(hipStream_t st, double* A, double* X, double* tm
                                 int n, int do_chol, int* info) {
   hipError_t e;
   if (n <= LEAF) {
-    (void)chain_launch<CK_LEAF64>(st, dim3(batch), A, X, ld, stride, off, n, do_chol, info, 0);
+    (void)chain_launch<leaf_potrf_inv_64_kernel>(st, dim3(batch), A, X, ld, stride, off, n, do_chol, info, 0);
     return hipGetLastError();
   }
   int n1 = ((n / 2 + 15) / 16) * 16;
@@ -74,7 +74,7 @@ static hipError_t potrf_inv_rec(hipStream_t st, double* A, double* X, double* tm
     // A21 <- L21 : copy T -> A21 as  A21 = T * I  is wasteful; use a strided 2D copy per batch
     {
       const long nc = (long)n2 * n1;
-      (void)chain_launch<CK_COPY_BLOCK>(st, dim3((unsigned)((nc + 255) / 256), batch), T, A21, ld, stride, n2, n1);
+      (void)chain_launch<copy_block_kernel>(st, dim3((unsigned)((nc + 255) / 256), batch), T, A21, ld, stride, n2, n1);
       if ((e = hipGetLastError()) != hipSuccess) return e;
     }
   }
@@ -85,14 +85,14 @@ static hipError_t potrf_inv_rec(hipStream_t st, double* A, double* X, double* tm
   // clean upper-right blocks (structural zeros are relied upon by the triangular hints of the GEMMs)
   const long nz = (long)n1 * n2;
   if (do_chol)
-    (void)chain_launch<CK_ZERO_BLOCK>(st, dim3((unsigned)((nz + 255) / 256), batch), A, ld, stride, off, off + n1, n1, n2);
-  (void)chain_launch<CK_ZERO_BLOCK>(st, dim3((unsigned)((nz + 255) / 256), batch), X, ld, stride, off, off + n1, n1, n2);
+    (void)chain_launch<zero_block_kernel>(st, dim3((unsigned)((nz + 255) / 256), batch), A, ld, stride, off, off + n1, n1, n2);
+  (void)chain_launch<zero_block_kernel>(st, dim3((unsigned)((nz + 255) / 256), batch), X, ld, stride, off, off + n1, n1, n2);
   return hipGetLastError();
 }
 
 hipError_t potrf_inv(hipStream_t st, double* A, double* X, double* tmp, int Mp, int batch, int* info, int n_act) {
   if (Mp <= LEAF && n_act > 0 && n_act <= 32) {      // A = blockdiag(A[:n, :n], I): only the leading block is factorised
-    (void)chain_launch<CK_LEAF32>(st, dim3(batch), A, X, Mp, (long)Mp * Mp, 0, n_act, 1, info, Mp);
+    (void)chain_launch<leaf_potrf_inv_32_kernel>(st, dim3(batch), A, X, Mp, (long)Mp * Mp, 0, n_act, 1, info, Mp);
     return hipGetLastError();
   }
   return potrf_inv_rec(st, A, X, tmp, Mp, (long)Mp * Mp, batch, 0, Mp, 1, info);
@@ -106,7 +106,7 @@ hipError_t trinv_lower(hipStream_t st, const double* L, double* X, double* tmp, 
 hipError_t pack_q(hipStream_t st, const double* q_sqrt, const double* q_mu, int M, int Mp, int D, double* Lq,
                   double* qmu_p) {
   const long n = (long)D * Mp * Mp;
-  (void)chain_launch<CK_PACK_Q>(st, dim3((unsigned)((n + 255) / 256)), q_sqrt, q_mu, M, Mp, D, Lq, qmu_p);
+  (void)chain_launch<pack_q_kernel>(st, dim3((unsigned)((n + 255) / 256)), q_sqrt, q_mu, M, Mp, D, Lq, qmu_p);
   LAUNCH_CHECK();
 }
 
@@ -131,23 +131,23 @@ hipError_t store_q(hipStream_t st, const double* Lq, const double* qmu_p, int M,
 
 hipError_t lq_to_wcat(hipStream_t st, const double* Lq, int Mp, int D, double* Wcat) {
   const long n = (long)D * Mp * Mp;
-  (void)chain_launch<CK_LQ_TO_WCAT>(st, dim3((unsigned)((n + 255) / 256)), Lq, Mp, D, Wcat);
+  (void)chain_launch<lq_to_wcat_kernel>(st, dim3((unsigned)((n + 255) / 256)), Lq, Mp, D, Wcat);
   LAUNCH_CHECK();
 }
 
 hipError_t copy_2d(hipStream_t st, const double* src, long lds, double* dst, long ldd, int nr, int nc) {
   const long n = (long)nr * nc;
-  (void)chain_launch<CK_COPY2D>(st, dim3((unsigned)((n + 255) / 256)), src, lds, dst, ldd, nr, nc);
+  (void)chain_launch<copy_2d_kernel>(st, dim3((unsigned)((n + 255) / 256)), src, lds, dst, ldd, nr, nc);
   LAUNCH_CHECK();
 }
 hipError_t copy_mat(hipStream_t st, const double* src, double* dst, long n) {
-  (void)chain_launch<CK_COPY>(st, dim3((unsigned)((n + 255) / 256)), src, dst, n);
+  (void)chain_launch<copy_kernel>(st, dim3((unsigned)((n + 255) / 256)), src, dst, n);
   LAUNCH_CHECK();
 }
 
 hipError_t make_z1(hipStream_t st, const double* Z, int M, int Mp, int Din, double* Z1) {
   const long n = (long)Mp * (Din + 1);
-  (void)chain_launch<CK_MAKE_Z1>(st, dim3((unsigned)((n + 255) / 256)), Z, M, Mp, Din, Z1);
+  (void)chain_launch<make_z1_kernel>(st, dim3((unsigned)((n + 255) / 256)), Z, M, Mp, Din, Z1);
   LAUNCH_CHECK();
 }
 
@@ -155,31 +155,31 @@ hipError_t make_z1(hipStream_t st, const double* Z, int M, int Mp, int Din, doub
 hipError_t rbf_kuf_bwd_finish(hipStream_t st, const double* GX, const double* x2rs, const double* vsum, const double* Z,
                               const double* var, const double* ls, int M, int Din, double* dZ, double* dls, double* dvar,
                               const double* kdot) {
-  (void)chain_launch<CK_KUF_BWD_FINISH>(st, dim3(Din), GX, x2rs, vsum, Z, var, ls, M, Din, dZ, dls, dvar, kdot);
+  (void)chain_launch<rbf_kuf_bwd_finish_kernel>(st, dim3(Din), GX, x2rs, vsum, Z, var, ls, M, Din, dZ, dls, dvar, kdot);
   LAUNCH_CHECK();
 }
 
 hipError_t lower_dot(hipStream_t st, const double* Lu, const double* Q, int M, int Mp, double* out) {
   if (chain_recorder()) {
-    (void)chain_launch<CK_ZERO1>(st, dim3(1), out, 1L);
+    (void)chain_launch<zero_doubles_kernel>(st, dim3(1), out, 1L);
   } else {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
     if (e != hipSuccess) return e;
   }
-  (void)chain_launch<CK_LOWER_DOT>(st, dim3(Mp <= 64 ? 1 : 16), Lu, Q, M, Mp, out);
+  (void)chain_launch<lower_dot_kernel>(st, dim3(Mp <= 64 ? 1 : 16), Lu, Q, M, Mp, out);
   LAUNCH_CHECK();
 }
 
 // WT[(d*Mp + j)*Mp + i] = Wcat[i*(D*Mp) + d*Mp + j]: the W_d^T stacked vertically ([D*Mp x Mp]), the B operand of
 // dC = [2 vbar .* T] * WTcat when t_d = W_d^T c is kept from the forward pass
 hipError_t wcat_transpose(hipStream_t st, const double* Wcat, int Mp, int D, double* WT) {
-  (void)chain_launch<CK_WCAT_T>(st, dim3(Mp / 32, Mp / 32, D), Wcat, Mp, D, WT);
+  (void)chain_launch<wcat_transpose_kernel>(st, dim3(Mp / 32, Mp / 32, D), Wcat, Mp, D, WT);
   LAUNCH_CHECK();
 }
 
 hipError_t sub_identity(hipStream_t st, double* S, int M, int Mp, int batch) {
   const long n = (long)batch * Mp * Mp;
-  (void)chain_launch<CK_SUB_IDENTITY>(st, dim3((unsigned)((n + 255) / 256)), S, M, Mp, n);
+  (void)chain_launch<sub_identity_kernel>(st, dim3((unsigned)((n + 255) / 256)), S, M, Mp, n);
   LAUNCH_CHECK();
 }
 
@@ -188,12 +188,12 @@ hipError_t sub_identity(hipStream_t st, double* S, int M, int Mp, int batch) {
 // had left it in HBM: 167 us for 8 x 256^2, on the critical path of the last layer's chain), diagonal tiles in place.
 hipError_t symmetrize_lower(hipStream_t st, double* G, int Mp, int batch) {
   const int nb = Mp / 32;
-  (void)chain_launch<CK_SYMMETRIZE>(st, dim3((unsigned)(nb * (nb + 1) / 2), (unsigned)batch), G, Mp);
+  (void)chain_launch<symmetrize_lower_kernel>(st, dim3((unsigned)(nb * (nb + 1) / 2), (unsigned)batch), G, Mp);
   LAUNCH_CHECK();
 }
 
 hipError_t sub_scalars(hipStream_t st, const double* a, const double* b, double* out) {
-  (void)chain_launch<CK_SUB_SCALARS>(st, dim3(1), a, b, out);
+  (void)chain_launch<sub_scalars_kernel>(st, dim3(1), a, b, out);
   LAUNCH_CHECK();
 }
 
@@ -212,7 +212,7 @@ __device__ __forceinline__ double block_sum_1024(double v, double* sh) {
 
 hipError_t layer_kl(hipStream_t st, const double* Wcat, const double* u, const double* Lq, const double* Lu, int M,
                     int Mp, int D, int white, double* kl_out) {
-  (void)chain_launch<CK_LAYER_KL>(st, dim3(Mp <= 64 ? 1 : 64), Wcat, u, Lq, Lu, M, Mp, D, white, kl_out);   // (grid-stride loops: one block covers a small layer)
+  (void)chain_launch<layer_kl_kernel>(st, dim3(Mp <= 64 ? 1 : 64), Wcat, u, Lq, Lu, M, Mp, D, white, kl_out);   // (grid-stride loops: one block covers a small layer)
   LAUNCH_CHECK();
 }
 
@@ -220,26 +220,26 @@ hipError_t layer_kl(hipStream_t st, const double* Wcat, const double* u, const d
 hipError_t wbar_total(hipStream_t st, double* dWcat, const double* Wcat, double* du, const double* u, int M, int Mp,
                       int D) {
   const long n = (long)Mp * D * Mp;
-  (void)chain_launch<CK_WBAR_TOTAL>(st, dim3((unsigned)((n + 255) / 256)), dWcat, Wcat, du, u, M, Mp, D);
+  (void)chain_launch<wbar_total_kernel>(st, dim3((unsigned)((n + 255) / 256)), dWcat, Wcat, du, u, M, Mp, D);
   LAUNCH_CHECK();
 }
 
 hipError_t lqbar_finish(hipStream_t st, double* dLq, const double* Lq, int M, int Mp, int D) {
   const long n = (long)D * Mp * Mp;
-  (void)chain_launch<CK_LQBAR>(st, dim3((unsigned)((n + 255) / 256)), dLq, Lq, M, Mp, D);
+  (void)chain_launch<lqbar_finish_kernel>(st, dim3((unsigned)((n + 255) / 256)), dLq, Lq, M, Mp, D);
   LAUNCH_CHECK();
 }
 
 hipError_t lubar_finish(hipStream_t st, double* dLu, const double* T2, const double* Lu, int M, int Mp, int D,
                         int white) {
   const long n = (long)Mp * Mp;
-  (void)chain_launch<CK_LUBAR>(st, dim3((unsigned)((n + 255) / 256)), dLu, T2, Lu, M, Mp, D, white);
+  (void)chain_launch<lubar_finish_kernel>(st, dim3((unsigned)((n + 255) / 256)), dLu, T2, Lu, M, Mp, D, white);
   LAUNCH_CHECK();
 }
 
 hipError_t phi_tril_halfdiag(hipStream_t st, double* T, int Mp, int batch) {
   const long n = (long)batch * Mp * Mp;
-  (void)chain_launch<CK_PHI>(st, dim3((unsigned)((n + 255) / 256)), T, Mp, n);
+  (void)chain_launch<phi_tril_halfdiag_kernel>(st, dim3((unsigned)((n + 255) / 256)), T, Mp, n);
   LAUNCH_CHECK();
 }
 
@@ -247,14 +247,14 @@ hipError_t phi_tril_halfdiag(hipStream_t st, double* T, int Mp, int batch) {
 hipError_t rbf_kuu_bwd(hipStream_t st, const double* S, const double* Kuu, const double* Euu, const double* Z,
                        const double* var, const double* ls, int M, int Mp, int Din, double* dZ, double* dls, double* dvar,
                        const double* white) {
-  (void)chain_launch<CK_KUU_BWD>(st, dim3(M, Din), S, Kuu, Euu, Z, var, ls, M, Mp, Din, dZ, dls, dvar, white);
+  (void)chain_launch<rbf_kuu_bwd_kernel>(st, dim3(M, Din), S, Kuu, Euu, Z, var, ls, M, Mp, Din, dZ, dls, dvar, white);
   LAUNCH_CHECK();
 }
 
 hipError_t unpack_q_grads(hipStream_t st, const double* dLq, const double* dqmu_p, int M, int Mp, int D,
                           double* g_q_sqrt, double* g_q_mu) {
   const long n = (long)D * M * M;
-  (void)chain_launch<CK_UNPACK_Q>(st, dim3((unsigned)((n + 255) / 256)), dLq, dqmu_p, M, Mp, D, g_q_sqrt, g_q_mu);
+  (void)chain_launch<unpack_q_grads_kernel>(st, dim3((unsigned)((n + 255) / 256)), dLq, dqmu_p, M, Mp, D, g_q_sqrt, g_q_mu);
   LAUNCH_CHECK();
 }
 
