@@ -524,6 +524,11 @@ int upload_zs(dgp_ctx* ctx, const double* const* zs, int S, long Ntot) {
 
 inline const double* P(dgp_ctx* ctx, long off) { return ctx->params + off; }
 
+// a layer whose per-point work runs in the fused small-model kernels (forward AND backward: they share the row-major t_d)
+bool small_fused(const dgp_ctx* ctx, const Layer& y) {
+  return ctx->store_t && y.d.kernel_kind != DGP_KERNEL_MF && small_layer_ok(y.d.kernel_kind, y.Mp, y.d.D_out, y.d.D_in);
+}
+
 // ------------------------------------------------------------------------------- recorded chains (small models)
 enum ChainKind : int { CHAIN_PREP = 0, CHAIN_PREP_TRAIN = 1, CHAIN_FINISH = 2 };
 
@@ -607,6 +612,16 @@ int prep_layer_launches(dgp_ctx* ctx, size_t li, bool train) {
 }
 
 int prep_layer(dgp_ctx* ctx, size_t li, bool train) {
+  {
+    Layer& y = ctx->L[li];
+    if (small_fused(ctx, y) && y.off_white < 0 && !ctx->chain_on) {      // at most 64 inducing points: one launch (small_layer.hip)
+      ProfScope ps(ctx, 2, 0, 0);
+      HIPCHK(small_prep(ctx->st, P(ctx, y.off_qsqrt), P(ctx, y.off_qmu), P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), y.d.M,
+                        y.d.D_out, y.d.D_in, y.d.kernel_kind, y.d.white, train ? 1 : 0, y.Lq, y.qmu_p, y.Kuu, train ? y.Euu : nullptr,
+                        y.Lu, y.Linv, y.LinvT, y.Wcat, y.u, train ? y.Scat : nullptr, train ? y.Z1 : nullptr, ctx->scal, ctx->info));
+      return DGP_OK;
+    }
+  }
   return run_chain(ctx, train ? CHAIN_PREP_TRAIN : CHAIN_PREP, li, [&]() { return prep_layer_launches(ctx, li, train); });
 }
 
@@ -744,11 +759,6 @@ GemmArgs args_g(long Pm, int Mp, const double* Cbar, const double* Linv, double*
   a.tri = TRI_B_LOWER; a.triblk = Mp;
   if (emul) { a.emul = emul; a.C2 = Gt; a.c2_only = 1; }
   return a;
-}
-
-// a layer whose per-point work runs in the fused small-model kernels (forward AND backward: they share the row-major t_d)
-bool small_fused(const dgp_ctx* ctx, const Layer& y) {
-  return ctx->store_t && y.d.kernel_kind != DGP_KERNEL_MF && small_layer_ok(y.d.kernel_kind, y.Mp, y.d.D_out, y.d.D_in);
 }
 
 // mean (before the mean function) = Ct u, and its adjoint reduction over the points du += Ct^T mbar

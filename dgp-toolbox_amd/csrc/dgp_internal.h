@@ -166,6 +166,11 @@ hipError_t small_layer_sums(hipStream_t st, long P, int Din, int D, const double
                             const double* vbar, const double* mbar, const double* X1, double* accG, double* accQ, double* accdu,
                             double* accGX, double* ws /* >= small_layer_sums_ws_doubles() */);
 long small_layer_sums_ws_doubles();
+// the layer's small-matrix preparation (prep_layer's chain) in one launch, Mp = 64
+hipError_t small_prep(hipStream_t st, const double* q_sqrt, const double* q_mu, const double* Z, const double* var, const double* ls,
+                      int M, int D, int Din, int kind, int white, int train, double* Lq, double* qmu_p, double* Kuu, double* Euu,
+                      double* Lu, double* Linv, double* LinvT, double* Wcat, double* u, double* Scat /* null: not wanted */,
+                      double* Z1 /* null: not wanted */, double* kl_out, int* info);
 hipError_t make_x1(hipStream_t st, const double* Xin, long x_row0, long P, int Din, double* X1);     // [X | 1]
 hipError_t xbar_finish(hipStream_t st, const double* R1, const double* X1, long P, const double* ls, int Din, int D,
                        int mean_kind, const double* meanW, const double* mbar, int want_xbar, double* xbar,

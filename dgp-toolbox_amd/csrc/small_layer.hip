@@ -12,6 +12,7 @@
 // Outputs have the layouts the unfused path uses (Kt, Ct, Cbar, Gt point-major [P][64]; T row-major [P][D * 64]; one
 // row-norm plane), so finalize_layer, xbar_finish, fold and the small-matrix chains run unchanged behind them.
 #include "dgp_internal.h"
+#include "chain_bodies.h"
 
 namespace dgp {
 
@@ -341,6 +342,160 @@ static int pts_per_block_for(long P) {
   long ppb = 4 * SL_Q;
   while (ppb < 4096 && (P + ppb - 1) / ppb > 512) ppb += 4 * SL_Q;
   return (int)ppb;
+}
+
+// ---------------------------------------------------------------------------------------------------- the layer's small matrices
+// One workgroup, one launch, for a layer with Mp = 64: what prep_layer (dgp_ctx.h) issues as 11 dependent launches -
+// pack_q, Kuu (+ jitter), Cholesky + inverse (the register-resident leaf, wave 0), Linv^T, W_d = Lu^-1 L_q,d, u = Lu^-1 q_mu,
+// KL (layers.py:280-308), W_d^T stacked and [Z | 1] for the backward pass.  The 64 x 64 operands of the products stay in LDS
+// between the steps; every output array the rest of the pass reads is written exactly as the separate kernels write it.
+struct SmallPrepArgs {
+  const double *q_sqrt, *q_mu, *Z, *var, *ls;
+  int M, D, Din, kind, white, train;
+  double *Lq, *qmu_p, *Kuu, *Euu, *Lu, *Linv, *LinvT, *Wcat, *u, *Scat, *Z1, *kl_out;
+  int* info;
+};
+
+__global__ __launch_bounds__(256) void small_prep_kernel(SmallPrepArgs a) {
+  __shared__ double sLi[SL_M][SL_M + 1];       // Linv (pitch 65: rows 4 ty + i of the 16 ty are on different banks)
+  __shared__ double sLq[SL_M][SL_M];           // L_q,d
+  __shared__ double sU[SL_M * SL_MAXD];        // q_mu padded [64][D]
+  __shared__ double sred[4];
+  const int tid = threadIdx.x, M = a.M, D = a.D, Din = a.Din;
+  const int Mp = SL_M;
+  // 1. L_q (padded: identity), q_mu (padded: zero)
+  for (int idx = tid; idx < D * Mp * Mp; idx += 256) {
+    const int d = idx / (Mp * Mp), i = (idx / Mp) % Mp, j = idx % Mp;
+    double v;
+    if (i < M && j < M) v = (j <= i) ? a.q_sqrt[((long)d * M + i) * M + j] : 0.0;
+    else v = (i == j) ? 1.0 : 0.0;
+    a.Lq[idx] = v;
+  }
+  for (int idx = tid; idx < Mp * D; idx += 256) {
+    const int i = idx / D, d = idx % D;
+    const double v = (i < M) ? a.q_mu[(long)i * D + d] : 0.0;
+    a.qmu_p[idx] = v;
+    sU[idx] = v;
+  }
+  // 2. Kuu + jitter (padding: identity) -> Kuu and the Cholesky's work copy Lu
+  for (int idx = tid; idx < Mp * Mp; idx += 256) {
+    const int m = idx / Mp, n = idx % Mp;
+    double v, e = 0.0;
+    if (m < M && n < M) {
+      double r2 = 0.0;
+      for (int j = 0; j < Din; ++j) {
+        const double d = (a.Z[(long)m * Din + j] - a.Z[(long)n * Din + j]) / a.ls[j];
+        r2 += d * d;
+      }
+      stationary_k(a.kind, a.var[0], r2, v, e);
+      v += (m == n ? kJitter : 0.0);
+    } else {
+      v = (m == n) ? 1.0 : 0.0;
+    }
+    a.Kuu[idx] = v;
+    a.Lu[idx] = v;
+    if (a.Euu) a.Euu[idx] = e;
+  }
+  __syncthreads();
+  // 3. Lu = chol(Kuu), Linv = Lu^-1: the leaf of potrf_inv (same choice of leaf as the host dispatcher makes), on wave 0
+  if (tid < 64) {
+    const VIdx b0{0u, 0u, 0u}, g1{1u, 1u, 1u}, t{(unsigned)tid, 0u, 0u}, bd{64u, 1u, 1u};
+    if (M <= 32) ChainBody<CK_LEAF32>::run<CM_CHAIN_WAVE>(b0, g1, t, bd, a.Lu, a.Linv, Mp, (long)Mp * Mp, 0, M, 1, a.info, Mp);
+    else ChainBody<CK_LEAF64>::run<CM_CHAIN_WAVE>(b0, g1, t, bd, a.Lu, a.Linv, Mp, (long)Mp * Mp, 0, Mp, 1, a.info, 0);
+  }
+  __syncthreads();
+  // 4. Linv -> LDS, Linv^T -> memory
+  for (int idx = tid; idx < Mp * Mp; idx += 256) {
+    const int i = idx / Mp, j = idx % Mp;
+    const double v = a.Linv[idx];
+    sLi[i][j] = v;
+    a.LinvT[(long)j * Mp + i] = v;
+  }
+  __syncthreads();
+  // 5. W_d = Linv L_q,d (white: L_q,d), its transpose stacked, 0.5 |W|^2 over the M x M part;  u = Linv q_mu (white: q_mu)
+  const int tx = tid & 15, ty = tid >> 4;
+  double kl = 0.0;
+  for (int d = 0; d < D; ++d) {
+    for (int idx = tid; idx < Mp * Mp; idx += 256) sLq[idx / Mp][idx % Mp] = a.Lq[(long)d * Mp * Mp + idx];
+    __syncthreads();
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    if (a.white) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = sLq[4 * ty + i][4 * tx + j];
+    } else {
+      for (int k = 0; k < Mp; ++k) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { av[i] = sLi[4 * ty + i][k]; bv[i] = sLq[k][4 * tx + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = fma(av[i], bv[j], acc[i][j]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = 4 * ty + i, n = 4 * tx + j;
+        const double w = acc[i][j];
+        a.Wcat[(long)m * D * Mp + (long)d * Mp + n] = w;
+        if (a.Scat) a.Scat[((long)d * Mp + n) * Mp + m] = w;
+        if (m < M && n < M) kl += 0.5 * w * w;
+      }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < Mp * D; idx += 256) {
+    const int m = idx / D, d = idx % D;
+    double uv;
+    if (a.white) uv = sU[idx];
+    else {
+      uv = 0.0;
+      for (int k = 0; k < Mp; ++k) uv = fma(sLi[m][k], sU[k * D + d], uv);
+    }
+    a.u[idx] = uv;
+    if (m < M) kl += 0.5 * uv * uv;
+  }
+  // 6. the rest of the KL: -0.5 sum log L_q,ii^2 (+ D sum log Lu_ii) - 0.5 D M
+  for (int idx = tid; idx < D * M; idx += 256) {
+    const int d = idx / M, i = idx % M;
+    const double q = a.Lq[((long)d * Mp + i) * Mp + i];
+    kl -= 0.5 * log(q * q);
+  }
+  if (!a.white)
+    for (int i = tid; i < M; i += 256) kl += (double)D * log(a.Lu[(long)i * Mp + i]);
+  if (tid == 0) kl -= 0.5 * (double)D * (double)M;
+  for (int o = 32; o > 0; o >>= 1) kl += __shfl_down(kl, o);
+  if ((tid & 63) == 0) sred[tid >> 6] = kl;
+  __syncthreads();
+  if (tid == 0) unsafeAtomicAdd(a.kl_out, sred[0] + sred[1] + sred[2] + sred[3]);
+  // 7. [Z | 1] (backward pass)
+  if (a.Z1) {
+    const int w1 = Din + 1;
+    for (int idx = tid; idx < Mp * w1; idx += 256) {
+      const int m = idx / w1, j = idx % w1;
+      a.Z1[idx] = (m < M) ? (j < Din ? a.Z[(long)m * Din + j] : 1.0) : 0.0;
+    }
+  }
+}
+
+hipError_t small_prep(hipStream_t st, const double* q_sqrt, const double* q_mu, const double* Z, const double* var, const double* ls,
+                      int M, int D, int Din, int kind, int white, int train, double* Lq, double* qmu_p, double* Kuu, double* Euu,
+                      double* Lu, double* Linv, double* LinvT, double* Wcat, double* u, double* Scat, double* Z1, double* kl_out,
+                      int* info) {
+  SmallPrepArgs a;
+  a.q_sqrt = q_sqrt; a.q_mu = q_mu; a.Z = Z; a.var = var; a.ls = ls;
+  a.M = M; a.D = D; a.Din = Din; a.kind = kind; a.white = white; a.train = train;
+  a.Lq = Lq; a.qmu_p = qmu_p; a.Kuu = Kuu; a.Euu = Euu; a.Lu = Lu; a.Linv = Linv; a.LinvT = LinvT; a.Wcat = Wcat; a.u = u;
+  a.Scat = Scat; a.Z1 = Z1; a.kl_out = kl_out; a.info = info;
+  hipLaunchKernelGGL(small_prep_kernel, dim3(1), dim3(256), 0, st, a);
+  return hipGetLastError();
 }
 
 bool small_layer_ok(int kind, int Mp, int D, int Din) {
