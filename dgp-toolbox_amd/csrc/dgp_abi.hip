@@ -594,6 +594,19 @@ static int finish_layer_launches(dgp_ctx* ctx, size_t li) {
 }
 
 static int finish_layer(dgp_ctx* ctx, size_t li) {
+  {
+    Layer& y = ctx->L[li];
+    if (small_fused(ctx, y) && y.off_white < 0 && !ctx->chain_on) {      // at most 64 inducing points: one launch (small_layer.hip)
+      double* acc = ctx->acc;
+      double* g = ctx->grad;
+      ProfScope ps(ctx, 2, 0, 0);
+      HIPCHK(small_finish(ctx->st, acc + y.acc_G, acc + y.acc_du, acc + y.acc_Q, acc + y.acc_GX, acc + y.acc_x2, acc + y.acc_dvar,
+                          y.Wcat, y.u, y.Linv, y.Lu, y.Lq, y.Kuu, y.Euu, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), y.d.M,
+                          y.d.D_out, y.d.D_in, y.d.white, y.dLq, y.dqmu_p, g + y.off_Z, g + y.off_ls, g + y.off_var, g + y.off_qsqrt,
+                          g + y.off_qmu, y.kdot));
+      return DGP_OK;
+    }
+  }
   return run_chain(ctx, CHAIN_FINISH, li, [&]() { return finish_layer_launches(ctx, li); });
 }
 

@@ -166,6 +166,12 @@ hipError_t small_layer_sums(hipStream_t st, long P, int Din, int D, const double
                             const double* vbar, const double* mbar, const double* X1, double* accG, double* accQ, double* accdu,
                             double* accGX, double* ws /* >= small_layer_sums_ws_doubles() */);
 long small_layer_sums_ws_doubles();
+// the layer's gradient finish (finish_layer's chain) in one launch, Mp = 64, stationary kernels without a White term
+hipError_t small_finish(hipStream_t st, const double* Gd, const double* du, const double* Qp, const double* GX, const double* x2,
+                        const double* vsum, const double* Wcat, const double* u, const double* Linv, const double* Lu,
+                        const double* Lq, const double* Kuu, const double* Euu, const double* Z, const double* var,
+                        const double* ls, int M, int D, int Din, int white, double* dLq, double* dqmu_p, double* gZ, double* gls,
+                        double* gvar, double* gqsqrt, double* gqmu, double* kdot);
 // the layer's small-matrix preparation (prep_layer's chain) in one launch, Mp = 64
 hipError_t small_prep(hipStream_t st, const double* q_sqrt, const double* q_mu, const double* Z, const double* var, const double* ls,
                       int M, int D, int Din, int kind, int white, int train, double* Lq, double* qmu_p, double* Kuu, double* Euu,

@@ -498,6 +498,254 @@ hipError_t small_prep(hipStream_t st, const double* q_sqrt, const double* q_mu, 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------- the layer's gradient finish
+// One workgroup, one launch, for a layer with Mp = 64: what finish_layer (dgp_abi.hip) issues as ~20 dependent launches - from
+// the layer's sums over the points (G_d, Q', du, g^T [X | 1], sum x^2 rowsum(g), sum vbar) to its entries of d ELBO / d params:
+//   dW_d = 2 sym(G_d) W_d - W_d (lower, M x M),  du' = du - u,  Q = Lu^-T Q',
+//   non-white: T1 = du' u^T + sum_d dW_d W_d^T, T2 = Lu^-T T1, dL_q,d = Lu^-T dW_d, dq_mu = Lu^-T du', dLu = -tril(Q + T2) - D diag(1 / Lu)
+//   white:     dL_q,d = dW_d, dq_mu = du', dLu = -tril(Q)
+//   dL_q,d += diag(1 / L_q,d) (KL),  Cholesky backward S = Lu^-T Phi(Lu^T dLu) Lu^-1,
+//   kernel gradients through Kuf (from g^T [X | 1]) and through Kuu (from sym(S)), SURVEY App. C steps 5-6.
+// The 64 x 64 operands live in LDS (four buffers of pitch 65); products: thread (ty, tx) owns a 4 x 4 block.
+struct SmallFinishArgs {
+  const double *Gd, *du, *Qp, *GX, *x2, *vsum;             // the layer's slice of the partial-sum buffer
+  const double *Wcat, *u, *Linv, *Lu, *Lq, *Kuu, *Euu;     // the layer's small matrices
+  const double *Z, *var, *ls;                              // parameters
+  int M, D, Din, white;
+  double *dLq, *dqmu_p;                                    // kept for the natural-gradient step
+  double *gZ, *gls, *gvar, *gqsqrt, *gqmu;                 // the layer's entries of the gradient
+  double* kdot;                                            // Matern kernels: sum_p dk_p . k_p  (null: squared exponential)
+};
+
+constexpr int SF_P = SL_M + 1;       // LDS pitch
+
+// acc[i][j] = sum_k opA(A)[4 ty + i][k] * opB(B)[k][4 tx + j],  A, B: LDS [64][SF_P];  TA: A is read transposed, TB likewise
+template <bool TA, bool TB>
+__device__ __forceinline__ void sf_mm(const double* __restrict__ A, const double* __restrict__ B, int ty, int tx, double (&acc)[4][4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+#pragma unroll 4
+  for (int k = 0; k < SL_M; ++k) {
+    double av[4], bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      av[i] = TA ? A[k * SF_P + 4 * ty + i] : A[(4 * ty + i) * SF_P + k];
+      bv[i] = TB ? B[(4 * tx + i) * SF_P + k] : B[k * SF_P + 4 * tx + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = fma(av[i], bv[j], acc[i][j]);
+  }
+}
+__device__ __forceinline__ void sf_store(double* __restrict__ C, int ty, int tx, const double (&acc)[4][4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) C[(4 * ty + i) * SF_P + 4 * tx + j] = acc[i][j];
+}
+__device__ __forceinline__ double sf_block_sum(double v, double* sh) {     // all 256 threads; result on every thread
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void small_finish_kernel(SmallFinishArgs a) {
+  __shared__ double sLi[SL_M * SF_P], sX[SL_M * SF_P], sY[SL_M * SF_P], sZ[SL_M * SF_P];
+  __shared__ double sDu[SL_M * SL_MAXD], sUu[SL_M * SL_MAXD], sh[4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int M = a.M, D = a.D, Din = a.Din, Mp = SL_M, w1 = Din + 1;
+  const bool white = a.white != 0;
+  for (int idx = tid; idx < Mp * Mp; idx += 256) sLi[(idx / Mp) * SF_P + idx % Mp] = a.Linv[idx];
+  for (int idx = tid; idx < Mp * D; idx += 256) {
+    const int i = idx / D;
+    const double uu = a.u[idx];
+    sUu[idx] = uu;
+    sDu[idx] = (i < M) ? a.du[idx] - uu : 0.0;             // du' (wbar_total)
+  }
+  __syncthreads();
+  double t1[4][4], acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t1[i][j] = 0.0;
+  for (int d = 0; d < D; ++d) {
+    // sX = sym(G_d) (the lower triangle is what the sums deliver), sY = W_d
+    for (int idx = tid; idx < Mp * Mp; idx += 256) {
+      const int i = idx / Mp, j = idx % Mp;
+      sX[i * SF_P + j] = a.Gd[(long)d * Mp * Mp + (i >= j ? (long)i * Mp + j : (long)j * Mp + i)];
+      sY[i * SF_P + j] = a.Wcat[(long)i * D * Mp + (long)d * Mp + j];
+    }
+    __syncthreads();
+    sf_mm<false, false>(sX, sY, ty, tx, acc);
+    __syncthreads();
+    // dW_d = tril(2 G W) - W on the M x M part (wbar_total) -> sZ
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 4 * ty + i, n = 4 * tx + j;
+        sZ[k * SF_P + n] = (k < M && n < M && n <= k) ? 2.0 * acc[i][j] - sY[k * SF_P + n] : 0.0;
+      }
+    __syncthreads();
+    if (!white) {
+      sf_mm<false, true>(sZ, sY, ty, tx, acc);              // dW_d W_d^T
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t1[i][j] += acc[i][j];
+      sf_mm<true, false>(sLi, sZ, ty, tx, acc);             // dL_q,d = Linv^T dW_d
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = sZ[(4 * ty + i) * SF_P + 4 * tx + j];
+    }
+    // lqbar_finish + unpack_q_grads
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * ty + i, c = 4 * tx + j;
+        double v = 0.0;
+        if (r < M && c <= r) v = acc[i][j] + (r == c ? 1.0 / a.Lq[((long)d * Mp + r) * Mp + r] : 0.0);
+        a.dLq[((long)d * Mp + r) * Mp + c] = v;
+        if (r < M && c < M) a.gqsqrt[((long)d * M + r) * M + c] = (c <= r) ? v : 0.0;
+      }
+    __syncthreads();
+  }
+  // dq_mu = Linv^T du' (white: du')  -> dqmu_p, gradient of q_mu
+  for (int idx = tid; idx < Mp * D; idx += 256) {
+    const int m = idx / D, d = idx % D;
+    double v;
+    if (white) v = sDu[idx];
+    else {
+      v = 0.0;
+      for (int k = 0; k < Mp; ++k) v = fma(sLi[k * SF_P + m], sDu[k * D + d], v);
+    }
+    a.dqmu_p[idx] = v;
+    if (m < M) a.gqmu[(long)m * D + d] = v;
+  }
+  // Q = Linv^T Q'
+  for (int idx = tid; idx < Mp * Mp; idx += 256) sY[(idx / Mp) * SF_P + idx % Mp] = a.Qp[idx];
+  __syncthreads();
+  double q[4][4];
+  sf_mm<true, false>(sLi, sY, ty, tx, q);
+  // Matern: kdot = sum_{i >= j < M} Lu[i][j] Q[i][j]   (before Q becomes dLu)
+  if (a.kdot) {
+    double kd = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * ty + i, c = 4 * tx + j;
+        if (r < M && c <= r) kd += a.Lu[(long)r * Mp + c] * q[i][j];
+      }
+    kd = sf_block_sum(kd, sh);
+    if (tid == 0) a.kdot[0] = kd;
+  }
+  __syncthreads();
+  if (!white) {
+    // T1 += du' u^T, T2 = Linv^T T1
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double v = t1[i][j];
+        for (int d = 0; d < D; ++d) v = fma(sDu[(4 * ty + i) * D + d], sUu[(4 * tx + j) * D + d], v);
+        sX[(4 * ty + i) * SF_P + 4 * tx + j] = v;
+      }
+    __syncthreads();
+    sf_mm<true, false>(sLi, sX, ty, tx, acc);               // T2
+  }
+  // dLu = -tril(Q + T2) - D diag(1 / Lu)   (lubar_finish) -> sZ;   Lu -> sX
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * ty + i, c = 4 * tx + j;
+      double v = 0.0;
+      if (r < M && c <= r) {
+        v = -(q[i][j] + (white ? 0.0 : acc[i][j]));
+        if (r == c && !white) v -= (double)D / a.Lu[(long)r * Mp + r];
+      }
+      sZ[r * SF_P + c] = v;
+    }
+  for (int idx = tid; idx < Mp * Mp; idx += 256) sX[(idx / Mp) * SF_P + idx % Mp] = a.Lu[idx];
+  __syncthreads();
+  // Cholesky backward: T3 = Phi(Lu^T dLu), T4 = T3 Linv, S = Linv^T T4
+  sf_mm<true, false>(sX, sZ, ty, tx, acc);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * ty + i, c = 4 * tx + j;
+      sY[r * SF_P + c] = (c < r) ? acc[i][j] : (r == c ? 0.5 * acc[i][j] : 0.0);
+    }
+  __syncthreads();
+  sf_mm<false, false>(sY, sLi, ty, tx, acc);
+  __syncthreads();
+  sf_store(sX, ty, tx, acc);
+  __syncthreads();
+  sf_mm<true, false>(sLi, sX, ty, tx, acc);
+  __syncthreads();
+  sf_store(sZ, ty, tx, acc);                                // S (unsymmetrised dKuu)
+  __syncthreads();
+  // kernel gradients: through Kuf (rbf_kuf_bwd_finish: writes) and through Kuu (rbf_kuu_bwd: adds)
+  const double v0 = a.var[0];
+  double vacc = 0.0;                                        // sum_{m, n} sym(S) k0   (variance through Kuu)
+  for (int j = 0; j < Din; ++j) {
+    const double l = a.ls[j];
+    double la = 0.0, va = 0.0, lk = 0.0;
+    if (tid < M) {
+      const int m = tid;
+      const double cs = a.GX[(long)m * w1 + Din], gx = a.GX[(long)m * w1 + j], z = a.Z[(long)m * Din + j];
+      double dz = -(z * cs - gx) / (l * l);
+      la = z * z * cs - 2.0 * z * gx;
+      va = cs;
+      double zacc = 0.0;
+      for (int n = 0; n < M; ++n) {
+        const double k0 = a.Kuu[(long)m * Mp + n] - (m == n ? kJitter : 0.0);
+        const double sym = 0.5 * (sZ[m * SF_P + n] + sZ[n * SF_P + m]);
+        const double h = sym * (a.Euu ? a.Euu[(long)m * Mp + n] : k0);
+        const double dl = z - a.Z[(long)n * Din + j];
+        zacc += h * dl;
+        lk += h * dl * dl;
+        if (j == 0) vacc += sym * k0;
+      }
+      dz += -2.0 * zacc / (l * l);
+      a.gZ[(long)m * Din + j] = dz;
+    }
+    const double lt = sf_block_sum(la, sh), lkt = sf_block_sum(lk, sh);
+    if (tid == 0) a.gls[j] = (lt + a.x2[j]) / (l * l * l) + lkt / (l * l * l);
+    if (j == 0) {
+      const double vt = sf_block_sum(va, sh), vk = sf_block_sum(vacc, sh);
+      if (tid == 0) a.gvar[0] = (a.kdot ? a.kdot[0] : vt) / v0 + a.vsum[0] + vk / v0;
+    }
+  }
+}
+
+hipError_t small_finish(hipStream_t st, const double* Gd, const double* du, const double* Qp, const double* GX, const double* x2,
+                        const double* vsum, const double* Wcat, const double* u, const double* Linv, const double* Lu,
+                        const double* Lq, const double* Kuu, const double* Euu, const double* Z, const double* var,
+                        const double* ls, int M, int D, int Din, int white, double* dLq, double* dqmu_p, double* gZ, double* gls,
+                        double* gvar, double* gqsqrt, double* gqmu, double* kdot) {
+  SmallFinishArgs a;
+  a.Gd = Gd; a.du = du; a.Qp = Qp; a.GX = GX; a.x2 = x2; a.vsum = vsum;
+  a.Wcat = Wcat; a.u = u; a.Linv = Linv; a.Lu = Lu; a.Lq = Lq; a.Kuu = Kuu; a.Euu = Euu;
+  a.Z = Z; a.var = var; a.ls = ls;
+  a.M = M; a.D = D; a.Din = Din; a.white = white;
+  a.dLq = dLq; a.dqmu_p = dqmu_p; a.gZ = gZ; a.gls = gls; a.gvar = gvar; a.gqsqrt = gqsqrt; a.gqmu = gqmu; a.kdot = kdot;
+  hipLaunchKernelGGL(small_finish_kernel, dim3(1), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 bool small_layer_ok(int kind, int Mp, int D, int Din) {
   static int enabled = -1;
   if (enabled < 0) { const char* e = getenv("DGP_SMALL_FUSED"); enabled = e ? atoi(e) : 1; }
