@@ -105,6 +105,11 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8192)
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Native libraries write to file descriptor 1 behind Python's back (RCCL prints a
+    # version banner when a communicator is created): everything but the final line is sent to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -233,7 +238,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, num_units, X, Y, Z)
             out["elbo_rel_err_vs_oracle"] = out["cpu_baseline"].pop("elbo_rel_err")
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()

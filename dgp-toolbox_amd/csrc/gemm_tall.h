@@ -49,7 +49,10 @@ constexpr int tl_pre(int p) { return (p <= 6 || (p >= 16 && p <= 22)) ? 4 : 0; }
 constexpr int tl_post(int p) { return (p == 15 || p == 23) ? 4 : 0; }
 constexpr int tl_allow(int p) { return 6 + tl_post((p + 22) % 24) + tl_pre((p + 23) % 24) + tl_post((p + 23) % 24); }
 
-template <bool STORE>
+// NT: the T stores carry the nontemporal hint (cache policy nt): 16 GB per 10^6 rows at D = 8 that nothing re-reads before the
+// backward pass would otherwise stream through the same 4 MB L2 that holds the Ct panel (read by the D pairs of a row tile)
+// and the W_d tiles
+template <bool STORE, bool NT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_tall_kernel(TallArgs g) {
   __shared__ __attribute__((aligned(1024))) char smem[TL_NSTAGE * TL_STAGE];
@@ -196,8 +199,8 @@ void gemm_tall_kernel(TallArgs g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const d2_t v0 = {acc[i][j][0], acc[i][j][1]}, v1 = {acc[i][j][2], acc[i][j][3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v0), rc, vo[i], 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v1), rc, vo[i] + 16, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v0), rc, vo[i], 0, NT ? 2 : 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v1), rc, vo[i] + 16, 0, NT ? 2 : 0);
       }
     }
     // The accumulators of the column restart from zero.  Written HERE by explicit moves: the MFMAs are inline asm (hipcc

@@ -33,8 +33,11 @@ hipError_t gemm_tall(hipStream_t st, const GemmArgs& a) {
   const long ntile = ((a.M + 255) / 256) * g.D;
   const long gmax = gemm_persistent_grid(a, cus);
   const unsigned grid = (unsigned)(ntile < gmax ? ntile : gmax);
-  if (g.C) hipLaunchKernelGGL(gemm_tall_kernel<true>, dim3(grid), dim3(512), 0, st, g);
-  else hipLaunchKernelGGL(gemm_tall_kernel<false>, dim3(grid), dim3(512), 0, st, g);
+  static int nt = -1;
+  if (nt < 0) { const char* e = getenv("DGP_TALL_NT"); nt = e ? atoi(e) : 1; }   // (same-box A/B: 50.51 -> 50.36 ms of point-contraction time per iteration)
+  if (g.C && nt) hipLaunchKernelGGL((gemm_tall_kernel<true, true>), dim3(grid), dim3(512), 0, st, g);
+  else if (g.C) hipLaunchKernelGGL((gemm_tall_kernel<true, false>), dim3(grid), dim3(512), 0, st, g);
+  else hipLaunchKernelGGL((gemm_tall_kernel<false, false>), dim3(grid), dim3(512), 0, st, g);
   return hipGetLastError();
 }
 
