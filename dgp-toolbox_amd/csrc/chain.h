@@ -28,10 +28,10 @@ struct VIdx { unsigned x, y, z; };
 
 // how a body's barrier is realised: a stand-alone kernel / a chain step run by all 256 threads: __syncthreads(); a chain
 // step whose (64-thread) virtual blocks are dealt to the four waves: the wave alone (LDS accesses of one wave are in order)
-enum ChainMode : int { CM_KERNEL = 0, CM_CHAIN = 1, CM_CHAIN_WAVE = 2 };
+enum ChainMode : int { CM_KERNEL = 0, CM_CHAIN = 1, CM_CHAIN_WAVE = 2, CM_WAVE_EXT = 3 };   // 3: one wave inside another kernel, which lends the LDS (g_body_ext)
 template <int MODE>
 __device__ __forceinline__ void body_sync() {
-  if constexpr (MODE == CM_CHAIN_WAVE) {
+  if constexpr (MODE == CM_CHAIN_WAVE || MODE == CM_WAVE_EXT) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   } else {

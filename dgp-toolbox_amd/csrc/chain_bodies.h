@@ -15,10 +15,13 @@ template <typename... T> struct ArgList {};
 // operand images of the small product), otherwise every inlined body would get an allocation of its own
 constexpr int kChainPoolBytes = 2 * 64 * 66 * 8;
 __shared__ __attribute__((aligned(16))) char g_chain_pool[kChainPoolBytes];
+__shared__ char* g_body_ext;          // CM_WAVE_EXT: the calling kernel's buffer (it sets the pointer before the call)
 template <int BYTES, int MODE>
 __device__ __forceinline__ char* body_smem() {
   static_assert(BYTES <= kChainPoolBytes, "chain LDS pool too small");
-  if constexpr (MODE == CM_KERNEL) {
+  if constexpr (MODE == CM_WAVE_EXT) {
+    return g_body_ext;
+  } else if constexpr (MODE == CM_KERNEL) {
     __shared__ __attribute__((aligned(16))) char buf[BYTES];
     return buf;
   } else {

@@ -894,6 +894,11 @@ int dgp_natgrad_step(dgp_ctx* ctx, double gamma, const uint8_t* layer_mask) {
     fork.use((int)l);
     const int M = y.d.M, Mp = y.Mp, D = y.d.D_out;
     const long MM = (long)Mp * Mp;
+    if (small_fused(ctx, y) && !ctx->capturing) {        // at most 64 inducing points: one launch (small_layer.hip)
+      HIPCHK(small_natgrad(ctx->st, y.Lq, y.dLq, y.dqmu_p, y.qmu_p, ctx->sm[0], ctx->sm[5], ctx->sm[6], ctx->params + y.off_qsqrt,
+                           ctx->params + y.off_qmu, gamma, M, D, ctx->info));
+      continue;
+    }
     double *Li = ctx->sm[0], *T = ctx->sm[1], *T1 = ctx->sm[2], *Gm = ctx->sm[3], *Pinv = ctx->sm[4], *Pn = ctx->sm[5],
            *Ri = ctx->sm[6], *Sn = ctx->sm[7];
     HIPCHK(trinv_lower(ctx->st, y.Lq, Li, ctx->sm[9], Mp, D));

@@ -166,6 +166,9 @@ hipError_t small_layer_sums(hipStream_t st, long P, int Din, int D, const double
                             const double* vbar, const double* mbar, const double* X1, double* accG, double* accQ, double* accdu,
                             double* accGX, double* ws /* >= small_layer_sums_ws_doubles() */);
 long small_layer_sums_ws_doubles();
+// one natural-gradient step of a layer's (q_mu, q_sqrt) in one launch (one workgroup per output), Mp = 64
+hipError_t small_natgrad(hipStream_t st, double* Lq, const double* dLq, const double* dqmu_p, double* qmu_p, double* w0, double* w1,
+                         double* w2, double* q_sqrt, double* q_mu, double gamma, int M, int D, int* info);
 // the layer's gradient finish (finish_layer's chain) in one launch, Mp = 64, stationary kernels without a White term
 hipError_t small_finish(hipStream_t st, const double* Gd, const double* du, const double* Qp, const double* GX, const double* x2,
                         const double* vsum, const double* Wcat, const double* u, const double* Linv, const double* Lu,

@@ -746,6 +746,113 @@ hipError_t small_finish(hipStream_t st, const double* Gd, const double* du, cons
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------- natural-gradient step
+// gpflow.optimizers.NaturalGradient(gamma) on one (q_mu, q_sqrt) pair of a layer with Mp = 64 (dgp.py:312-322,343; closed
+// form of SURVEY App. B), one workgroup per output d: what dgp_natgrad_step issues as 12 launches per layer -
+//   Li = L_q^-1,  dSigma = Li^T Phi(L_q^T dL_q) Li,  Sigma'^-1 = Li^T Li - 2 gamma sym(dSigma)   (loss = -ELBO),
+//   Ri = chol(Sigma'^-1)^-1,  Sigma' = Ri^T Ri,  mu' = mu + gamma Sigma' dmu,  L_q' = chol(Sigma').
+// The three factorisations / inversions are the register-resident leaf on wave 0 (operands through the scratch in memory).
+struct SmallNatArgs {
+  double* Lq;                 // [D][64][64] in / out
+  const double* dLq;          // [D][64][64]
+  const double* dqmu_p;       // [64][D]
+  double* qmu_p;              // [64][D] in / out
+  double *w0, *w1, *w2;       // scratch [D][64][64] each
+  double *q_sqrt, *q_mu;      // parameters out: [D][M][M], [M][D]
+  double gamma;
+  int M, D;
+  int* info;
+};
+
+__global__ __launch_bounds__(256) void small_natgrad_kernel(SmallNatArgs a) {
+  __shared__ double sLi[SL_M * SF_P], sX[SL_M * SF_P], sY[SL_M * SF_P], sZ[SL_M * SF_P];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4, d = blockIdx.x;
+  const int M = a.M, D = a.D, Mp = SL_M;
+  const long MM = (long)Mp * Mp;
+  double* Lq = a.Lq + d * MM;
+  const double* dLq = a.dLq + d * MM;
+  double *Li = a.w0 + d * MM, *Pn = a.w1 + d * MM, *Ri = a.w2 + d * MM;
+  const VIdx b0{0u, 0u, 0u}, g1{1u, 1u, 1u}, t{(unsigned)(tid & 63), 0u, 0u}, bd{64u, 1u, 1u};
+  if (tid == 0) g_body_ext = reinterpret_cast<char*>(sZ);       // the leaf's transpose buffer: sZ whenever the leaf runs
+  __syncthreads();
+  // Li = L_q^-1
+  if (tid < 64) ChainBody<CK_LEAF64>::run<CM_WAVE_EXT>(b0, g1, t, bd, Lq, Li, Mp, MM, 0, Mp, 0, a.info, 0);
+  __syncthreads();
+  for (int idx = tid; idx < Mp * Mp; idx += 256) {
+    const int i = idx / Mp, j = idx % Mp;
+    sLi[i * SF_P + j] = Li[idx];
+    sX[i * SF_P + j] = Lq[idx];
+    sY[i * SF_P + j] = dLq[idx];
+  }
+  __syncthreads();
+  double acc[4][4], pinv[4][4];
+  sf_mm<true, false>(sX, sY, ty, tx, acc);                  // L_q^T dL_q
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * ty + i, c = 4 * tx + j;
+      sZ[r * SF_P + c] = (c < r) ? acc[i][j] : (r == c ? 0.5 * acc[i][j] : 0.0);       // Phi
+    }
+  __syncthreads();
+  sf_mm<false, false>(sZ, sLi, ty, tx, acc);                // Phi Li
+  __syncthreads();
+  sf_store(sX, ty, tx, acc);
+  __syncthreads();
+  sf_mm<true, false>(sLi, sX, ty, tx, acc);                 // dSigma (unsymmetrised)
+  sf_mm<true, false>(sLi, sLi, ty, tx, pinv);               // Sigma^-1
+  __syncthreads();
+  sf_store(sY, ty, tx, acc);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * ty + i, c = 4 * tx + j;
+      Pn[(long)r * Mp + c] = pinv[i][j] + (-2.0 * a.gamma) * 0.5 * (sY[r * SF_P + c] + sY[c * SF_P + r]);
+    }
+  __syncthreads();
+  // Ri = chol(Sigma'^-1)^-1
+  if (tid < 64) ChainBody<CK_LEAF64>::run<CM_WAVE_EXT>(b0, g1, t, bd, Pn, Ri, Mp, MM, 0, Mp, 1, a.info, 0);
+  __syncthreads();
+  for (int idx = tid; idx < Mp * Mp; idx += 256) sX[(idx / Mp) * SF_P + idx % Mp] = Ri[idx];
+  __syncthreads();
+  sf_mm<true, false>(sX, sX, ty, tx, acc);                  // Sigma' = Ri^T Ri
+  __syncthreads();
+  sf_store(sZ, ty, tx, acc);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Lq[(long)(4 * ty + i) * Mp + 4 * tx + j] = acc[i][j];
+  __syncthreads();
+  // mu' = mu + gamma Sigma' dmu   (loss = -ELBO)
+  if (tid < M) {
+    double sacc = 0.0;
+    for (int n = 0; n < M; ++n) sacc += sZ[tid * SF_P + n] * a.dqmu_p[(long)n * D + d];
+    const double mu = a.qmu_p[(long)tid * D + d] + a.gamma * sacc;
+    a.qmu_p[(long)tid * D + d] = mu;
+    a.q_mu[(long)tid * D + d] = mu;
+  }
+  __syncthreads();
+  // L_q' = chol(Sigma')  (in place; its inverse goes to the scratch)
+  if (tid < 64) ChainBody<CK_LEAF64>::run<CM_WAVE_EXT>(b0, g1, t, bd, Lq, Li, Mp, MM, 0, Mp, 1, a.info, 0);
+  __syncthreads();
+  for (int idx = tid; idx < M * M; idx += 256) {
+    const int i = idx / M, j = idx % M;
+    a.q_sqrt[(long)d * M * M + idx] = (j <= i) ? Lq[(long)i * Mp + j] : 0.0;
+  }
+}
+
+hipError_t small_natgrad(hipStream_t st, double* Lq, const double* dLq, const double* dqmu_p, double* qmu_p, double* w0, double* w1,
+                         double* w2, double* q_sqrt, double* q_mu, double gamma, int M, int D, int* info) {
+  SmallNatArgs a;
+  a.Lq = Lq; a.dLq = dLq; a.dqmu_p = dqmu_p; a.qmu_p = qmu_p; a.w0 = w0; a.w1 = w1; a.w2 = w2; a.q_sqrt = q_sqrt; a.q_mu = q_mu;
+  a.gamma = gamma; a.M = M; a.D = D; a.info = info;
+  hipLaunchKernelGGL(small_natgrad_kernel, dim3(D), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 bool small_layer_ok(int kind, int Mp, int D, int Din) {
   static int enabled = -1;
   if (enabled < 0) { const char* e = getenv("DGP_SMALL_FUSED"); enabled = e ? atoi(e) : 1; }
