@@ -38,6 +38,8 @@ int dgp_create(int device, void* hip_stream, dgp_ctx** out) {
     ctx->store_t = !(t && t[0] == '0');
     const char* ch = getenv("DGP_CHAIN");
     ctx->chain_on = ch && ch[0] == '1';
+    const char* dg = getenv("DGP_DU_IN_GRAM");
+    ctx->du_in_gram = !(dg && dg[0] == '0');
     const char* bt = getenv("DGP_BLOCKED_T");
     ctx->blocked_t = !(bt && bt[0] == '0');
     bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -1140,39 +1142,49 @@ int dgp_dev_gemm(dgp_ctx* ctx, int32_t op, int64_t M, int64_t N, int64_t K, cons
   return rc;
 }
 
-int dgp_dev_gram(dgp_ctx* ctx, const double* C, const double* s, int64_t Pn, int32_t D, double* G) {
-  if (!ctx || !C || !G || Pn <= 0 || D < 1 || D > 64 || (!s && D != 1)) return fail(ctx, DGP_ERR_INVALID, "dgp_dev_gram: bad arguments");
+int dgp_dev_gram(dgp_ctx* ctx, const double* C, const double* s, int64_t Pn, int32_t D, double* G, const double* mb, double* du) {
+  if (!ctx || !C || !G || Pn <= 0 || D < 1 || D > 64 || (!s && D != 1) || ((mb != nullptr) != (du != nullptr)) || (mb && !s))
+    return fail(ctx, DGP_ERR_INVALID, "dgp_dev_gram: bad arguments");
   HIPCHK(hipSetDevice(ctx->device));
   const int Mp = 256;
   const long MM = (long)Mp * Mp;
-  double *dC = nullptr, *ds = nullptr, *dG = nullptr;
+  double *dC = nullptr, *ds = nullptr, *dG = nullptr, *dmb = nullptr, *ddu = nullptr;
+  struct Free { double **a, **b, **c, **d, **e; ~Free() { dev_free(*a); dev_free(*b); dev_free(*c); dev_free(*d); dev_free(*e); } } freer{&dC, &ds, &dG, &dmb, &ddu};
   RET(dev_alloc(ctx, &dC, (size_t)Pn * Mp));
   RET(dev_alloc(ctx, &dG, (size_t)D * MM));
   if (s) RET(dev_alloc(ctx, &ds, (size_t)Pn * D));
+  if (mb) { RET(dev_alloc(ctx, &dmb, (size_t)Pn * D)); RET(dev_alloc(ctx, &ddu, (size_t)Mp * D)); }
   if (!ctx->gram_ws) RET(dev_alloc(ctx, &ctx->gram_ws, gemm_gram_ws_bytes(ctx->cu_count) / 8));
   HIPCHK(hipMemcpy(dC, C, (size_t)Pn * Mp * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dG, G, (size_t)D * MM * 8, hipMemcpyHostToDevice));
   if (s) HIPCHK(hipMemcpy(ds, s, (size_t)Pn * D * 8, hipMemcpyHostToDevice));
-  // the call forward_chunk's backward makes (dgp_ctx.h: G_d)
-  GemmArgs a = mk(Mp, Mp, Pn, dC, Mp, dC, Mp, dG, Mp, 1.0, 1);
-  a.batch = D; a.sC = MM; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp) * D, Pn, (long)Mp * 8);
-  if (s) { a.ascale = ds; a.as_ld = D; a.ascale_mode = 2; }
-  a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = gemm_gram_ws_bytes(ctx->cu_count);
-  int rc = GX(ctx, 0, GEMM_TN, a);
-  if (rc == DGP_OK) {
-    HIPCHK(hipStreamSynchronize(ctx->st));
-    HIPCHK(hipMemcpy(G, dG, (size_t)D * MM * 8, hipMemcpyDeviceToHost));
+  if (mb) {
+    HIPCHK(hipMemcpy(dmb, mb, (size_t)Pn * D * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ddu, du, (size_t)Mp * D * 8, hipMemcpyHostToDevice));
   }
-  dev_free(dC); dev_free(dG); dev_free(ds);
-  return rc;
+  // the call backward_chunk makes (dgp_ctx.h: args_G; du = Ct^T mbar rides on it when the Gram kernel runs it)
+  GemmArgs a = s ? args_G(ctx, Pn, Mp, D, dC, ds, dG) : mk(Mp, Mp, Pn, dC, Mp, dC, Mp, dG, Mp, 1.0, 1);
+  if (!s) {
+    a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp), Pn, (long)Mp * 8);
+    a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = gemm_gram_ws_bytes(ctx->cu_count);
+  }
+  if (mb) {
+    if (gemm_engine_of(GEMM_TN, a) == 4) { a.gram_mb = dmb; a.gram_du = ddu; }
+    else RET(GX(ctx, 0, GEMM_TN, args_du(ctx, Pn, Mp, D, dC, dmb, ddu)));
+  }
+  RET(GX(ctx, 0, GEMM_TN, a));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  HIPCHK(hipMemcpy(G, dG, (size_t)D * MM * 8, hipMemcpyDeviceToHost));
+  if (mb) HIPCHK(hipMemcpy(du, ddu, (size_t)Mp * D * 8, hipMemcpyDeviceToHost));
+  return DGP_OK;
 }
 
 int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, const double* Kt, const double* Linv,
                            const double* Wcat, const double* u, const double* vbar, const double* mbar, double* Ct,
                            double* cn, double* T, double* tn, double* mean0, double* Cbar, double* g, double* du,
-                           int32_t* engines) {
+                           double* Gd, int32_t* engines) {
   if (!ctx || Pn <= 0 || Mp <= 0 || Mp % 64 != 0 || D < 1 || D > 64 || !Kt || !Linv || !Wcat || !u || !vbar || !mbar || !Ct || !cn ||
-      !T || !tn || !mean0 || !Cbar || !g || !du)
+      !T || !tn || !mean0 || !Cbar || !g || !du || !Gd)
     return fail(ctx, DGP_ERR_INVALID, "dgp_dev_layer_products: bad arguments");
   HIPCHK(hipSetDevice(ctx->device));
   const long P = Pn, Pm = pad_rows(P), MM = (long)Mp * Mp, DM = (long)D * Mp;
@@ -1185,7 +1197,9 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, cons
     return DGP_OK;
   };
   struct Free { std::vector<double*>& b; ~Free() { for (double* q : b) (void)hipFree(q); } } freer{bufs};
-  double *dKt, *dLinv, *dLinvT, *dW, *dS, *du_, *dvb, *dmb, *dCt, *cnp, *tnp, *dT, *dm0, *dCb, *dKb, *dG, *ddu;
+  double *dKt, *dLinv, *dLinvT, *dW, *dS, *du_, *dvb, *dmb, *dCt, *cnp, *tnp, *dT, *dm0, *dCb, *dKb, *dG, *ddu, *dGd;
+  if (Mp == 256 && !ctx->gram_ws) RET(dev_alloc(ctx, &ctx->gram_ws, gemm_gram_ws_bytes(ctx->cu_count) / 8));
+  RET(take(&dGd, (size_t)D * MM, true));
   RET(take(&dKt, (size_t)Pm * Mp, true)); RET(take(&dLinv, MM, false)); RET(take(&dLinvT, MM, false));
   RET(take(&dW, (size_t)Mp * DM, false)); RET(take(&dS, (size_t)Mp * DM, false)); RET(take(&du_, (size_t)Mp * D, false));
   RET(take(&dvb, (size_t)Pm * D, true)); RET(take(&dmb, (size_t)Pm * D, true));
@@ -1212,8 +1226,13 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, cons
   RET(GX(ctx, 0, GEMM_NN, aB));
   GemmArgs aG = args_g(Pm, Mp, dCb, dLinv, dKb, dKt, dG);
   RET(GX(ctx, 0, GEMM_NN, aG));
+  // du rides on G_d's launch when that one goes to the Gram kernel (backward_chunk)
   GemmArgs aU = args_du(ctx, P, Mp, D, dCt, dmb, ddu);
-  RET(GX(ctx, 0, GEMM_TN, aU));
+  GemmArgs aGd = args_G(ctx, P, Mp, D, dCt, dvb, dGd);
+  const bool du_in_gram = ctx->du_in_gram && gemm_engine_of(GEMM_TN, aGd) == 4;
+  if (du_in_gram) { aGd.gram_mb = dmb; aGd.gram_du = ddu; }
+  else RET(GX(ctx, 0, GEMM_TN, aU));
+  RET(GX(ctx, 0, GEMM_TN, aGd));
   if (engines) {
     GemmArgs c2 = aC, t2 = aT;
     if (!wide) { c2.B = dLinv; c2.no_wide = 1; t2.no_wide = 1; }
@@ -1221,7 +1240,8 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, cons
     engines[1] = gemm_engine_of(GEMM_NN, t2);
     engines[2] = gemm_engine_of(GEMM_NN, aB);
     engines[3] = gemm_engine_of(GEMM_NN, aG);
-    engines[4] = gemm_engine_of(GEMM_TN, aU);
+    engines[5] = gemm_engine_of(GEMM_TN, aGd);
+    engines[4] = du_in_gram ? engines[5] : gemm_engine_of(GEMM_TN, aU);
   }
   // results: row-norm planes summed as finalize_layer sums them, T taken out of the engine's blocked layout
   std::vector<double> hpl((size_t)Pm * maxpl * D), hT((size_t)Pm * DM);
@@ -1230,6 +1250,7 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, cons
   HIPCHK(hipMemcpyAsync(Cbar, dCb, (size_t)P * Mp * 8, hipMemcpyDeviceToHost, ctx->st));
   HIPCHK(hipMemcpyAsync(g, dG, (size_t)P * Mp * 8, hipMemcpyDeviceToHost, ctx->st));
   HIPCHK(hipMemcpyAsync(du, ddu, (size_t)Mp * D * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipMemcpyAsync(Gd, dGd, (size_t)D * MM * 8, hipMemcpyDeviceToHost, ctx->st));
   HIPCHK(hipMemcpyAsync(hT.data(), dT, (size_t)Pm * DM * 8, hipMemcpyDeviceToHost, ctx->st));
   HIPCHK(hipMemcpyAsync(hpl.data(), cnp, (size_t)Pm * nplane * 8, hipMemcpyDeviceToHost, ctx->st));
   HIPCHK(hipStreamSynchronize(ctx->st));

@@ -138,6 +138,7 @@ struct dgp_ctx {
   // chain contains a launch that cannot be recorded and runs launch by launch
   struct ChainProg { ChainOp* dev = nullptr; int n = 0; };
   std::map<long, ChainProg> chains;
+  bool du_in_gram = true;   // du = Ct^T mbar inside the Gram launch of G_d (gemm_gram.h, form DU); DGP_DU_IN_GRAM=0: a launch of its own
   bool chain_on = false;    // off: measured slower than launch by launch (NOTES.md, round 3); DGP_CHAIN=1 enables
   bool prep_deferred = false, prep_deferred_train = false;   // the upper layers' prep chains are still to be enqueued (prep_deferred_layers)
   // the backward pass's HBM-bound part on a low-priority stream beside its matrix-core-bound reductions (backward_chunk)
@@ -765,6 +766,15 @@ GemmArgs args_g(long Pm, int Mp, const double* Cbar, const double* Linv, double*
 GemmArgs args_mean0(long Pm, int Mp, int D, const double* Ct, const double* u, double* mean0) {
   return mk(Pm, D, Mp, Ct, Mp, u, D, mean0, D);
 }
+// G_d = sum_p vbar_pd c_p c_p^T (lower triangle, added to G): Mp = 256 on the Gram kernel (gemm_gram.h)
+GemmArgs args_G(dgp_ctx* ctx, long Pl, int Mp, int D, const double* Ct, const double* vbar, double* G) {
+  GemmArgs a = mk(Mp, Mp, Pl, Ct, Mp, Ct, Mp, G, Mp, 1.0, 1);
+  a.batch = D; a.sC = (long)Mp * Mp; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp) * D, Pl, (long)Mp * 8);
+  a.ascale = vbar; a.as_ld = D; a.ascale_mode = 2;
+  a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = ctx->gram_ws ? gemm_gram_ws_bytes(ctx->cu_count) : 0;
+  a.cu_count = ctx->cu_count; a.reserve_cus = ctx->reserved_cus;
+  return a;
+}
 GemmArgs args_du(dgp_ctx* ctx, long Pl, int Mp, int D, const double* Ct, const double* mbar, double* du) {
   GemmArgs a = mk(Mp, D, Pl, Ct, Mp, mbar, D, du, D, 1.0, 1);
   a.splits = pick_splits(ctx, Mp, D, Pl);
@@ -932,7 +942,12 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       GemmArgs a = args_g(Pm, Mp, ctx->Cbar, y.Linv, ctx->Kbar, y.d.kernel_kind != DGP_KERNEL_MF ? (y.Et ? y.Et : y.Kt) : nullptr, ctx->Gt);
       RET(GX(ctx, 0, GEMM_NN, a, tri1, (double)Pl * Mp * 32));
     }
-    if (o.params) {
+    // du = Ct^T mbar rides on the launch that streams Ct for G_d when that one goes to the Gram kernel (gemm_gram.h, form DU)
+    const int reserve = ovl ? (D >= 4 ? ctx->overlap_reserve_wide : ctx->overlap_reserve_narrow) : 0;
+    GemmArgs aG = args_G(ctx, Pl, Mp, D, y.Ct, y.vbar, acc + y.acc_G);
+    if (reserve > aG.reserve_cus) aG.reserve_cus = reserve;
+    const bool du_in_gram = o.params && ctx->du_in_gram && gemm_engine_of(GEMM_TN, aG) == 4;
+    if (o.params && !du_in_gram) {
       GemmArgs a = args_du(ctx, Pl, Mp, D, y.Ct, y.mbar, acc + y.acc_du);
       RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
     }
@@ -975,14 +990,10 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     }
     // reductions over the chunk's points (accumulate into the all-reduce buffer)
     if (o.params) {
-    const int reserve = ovl ? (D >= 4 ? ctx->overlap_reserve_wide : ctx->overlap_reserve_narrow) : 0;
     {  // G_d = sum_p vbar_pd c_p c_p^T   (lower triangle; dW_d = 2 G_d W_d after the all-reduce)
-      GemmArgs a = mk(Mp, Mp, Pl, y.Ct, Mp, y.Ct, Mp, acc + y.acc_G, Mp, 1.0, 1);
-      a.batch = D; a.sC = MM; a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp) * D, Pl, (long)Mp * 8);
-      a.ascale = y.vbar; a.as_ld = D; a.ascale_mode = 2;
-      a.gram_ws = ctx->gram_ws; a.gram_ws_bytes = ctx->gram_ws ? gemm_gram_ws_bytes(ctx->cu_count) : 0;     // (Mp = 256: gemm_gram.h)
-      a.reserve_cus = reserve;
-      RET(GX(ctx, 0, GEMM_TN, a, tri1 * D, (double)Pl * Mp * 8));
+      GemmArgs a = aG;
+      if (du_in_gram) { a.gram_mb = y.mbar; a.gram_du = acc + y.acc_du; }
+      RET(GX(ctx, 0, GEMM_TN, a, tri1 * D + (du_in_gram ? 2.0 * Pl * Mp * D : 0.0), (double)Pl * Mp * 8));
     }
     {
       // Q' = Cbar^T C (stationary kernels; Q = Linv^T Q' in finish_layer) or Q = dK^T C (composite kernel: dK is stored)

@@ -103,6 +103,11 @@ struct GemmArgs {
   int c2_only = 0;     // 1: only C2 = C .* emul is stored, C itself is not (overwrite semantics only: beta = 0, splits = 1)
   double* gram_ws = nullptr;   // scratch for gemm_gram.h's partial triangles (gram_ws_bytes >= gemm_gram_ws_bytes())
   long gram_ws_bytes = 0;
+  // weighted Gram launches only (gemm_gram.h, form DU): also gram_du[m][d] += sum_k gram_mb[k][d] B[k][m]  (batch = d; the
+  // adjoint of mean = c^T u_d riding on the launch that streams Ct for G_d).  Ignored - and the caller must issue that product
+  // itself - when the launch does not go to the Gram kernel (gemm_engine_of(...) != 4).
+  const double* gram_mb = nullptr;
+  double* gram_du = nullptr;
   int no_wide = 0;     // 1: keep this product on the 128 x 64 engine even where the wide-tile kernel (gemm_wide.h) applies
   // the device this launch is for, as its context knows it (0: ask the runtime for the current device's CU count), and the
   // CUs a persistent one-workgroup-per-CU kernel (wide-tile, tall-tile, Gram) leaves free for a collective that runs beside

@@ -23,6 +23,11 @@
 //     G_d in a fixed order - 71 MB of traffic per launch and a reproducible sum.  (Measured: 256 workgroups adding
 //     their triangles to the same G_d with fp64 atomics cost 0.23 ms per d, 1.9 of 9.3 ms at D = 8, and 2 GB of atomic
 //     traffic per launch for the 128 x 64 engine's 4096-point chunks.)
+//   * DU (weighted form): the launch also produces du_d = sum_p mbar[p][d] c_p (the adjoint of mean = c^T u_d, SURVEY App. C
+//     step 1: until round 3 a launch of its own that read Ct once more, 2 GB per 10^6 points).  Waves 0 and 1 own the
+//     sixteen row blocks between them (their two groups of four): they multiply the RAW A fragments they read anyway by
+//     mbar[k][d] - which travels with the k-tile like the weights, requested by wave 1 - on the VALU: 32 FMAs per wave and
+//     k-tile beside 272 MFMAs.  The 256 sums go out behind the segment's triangle (a 137th block of the slot).
 // Lane maps of v_mfma_f64_4x4x4_4b_f64: gemm_f64.h.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -56,11 +61,13 @@ struct GramArgs {
   const double* C;      // [P][256] point-major (Ct)
   const double* s;      // [P][D] weights (vbar), or nullptr = 1
   double* G;            // [D][256][256]: the lower triangles are ADDED to it (by gram_reduce_kernel)
-  double* ws;           // partial triangles: [2 * gridDim.x slots][136 blocks][64 lanes][4]  (GR_SLOT_BYTES each)
+  double* ws;           // partial triangles: [2 * gridDim.x slots][137 blocks][64 lanes][4]  (GR_SLOT_BYTES each; block 136: du)
   long P;               // points, a multiple of 16
   int D;                // 1..8
+  const double* mb;     // DU: [P][D] (mbar), and
+  double* du;           // [256][D]: du[m][d] += sum_p mb[p][d] C[p][m]
 };
-constexpr long GR_SLOT_DOUBLES = 136L * 256;
+constexpr long GR_SLOT_DOUBLES = 137L * 256;
 constexpr long GR_SLOT_BYTES = GR_SLOT_DOUBLES * 8;
 // Work split, XCD-grouped for ANY grid size G >= 8 D.  Workgroups are dealt round-robin to the 8 XCDs (b % 8, observed
 // placement; speed only): XCD x holds n_x = ceil((G - x) / 8) of them and gets a share n_x / G of the points (k-tiles
@@ -145,7 +152,7 @@ constexpr int gram_nblk(const GramMap& m) { return gram_blk(m, m.ng, 0, 0); }
 
 template <int W> struct GramMapOf { static constexpr GramMap m = gram_map(W); };
 
-template <int W, bool SC, int KH>
+template <int W, bool SC, int KH, bool DU>
 __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wave, int lane) {
   using GM = GramMapOf<W>;
   constexpr int NG = GM::m.ng, NS = gram_units(GM::m);
@@ -158,6 +165,9 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
   constexpr int SUBH = 4 / KH;                    // k-substeps per stage
   constexpr int IMG_B = KH == 2 ? 16384 : 0;      // the column operand's image inside a stage (the row operand's is at 0)
   static_assert(!(SC && KH == 2), "the weighted form has one source");
+  static_assert(!DU || SC, "du rides on the weighted form");
+  constexpr bool DUW = DU && W < 2;               // this wave accumulates du for its eight row blocks
+  static_assert(!DUW || (NG == 2 && GM::m.nr[0] == 4 && GM::m.nr[1] == 4), "waves 0 / 1: two groups of four row blocks");
   static_assert(U % 4 == 0 && GM::m.nc[NG - 1] >= 2, "slot ring / barrier placement");
   const int li = lane & 15, lk = lane >> 4;
   const int sw = lk & 1;
@@ -175,7 +185,7 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
   long kt_lo = 0;             // current segment: k-tiles [kt_lo, kt_lo + nkt) of output d
   int nkt = 0;
 
-  constexpr bool extra = SC && W == 0;      // this wave also requests the weights' piece
+  constexpr bool extra = (SC && W == 0) || (DU && W == 1);      // this wave also requests the weights' (wave 0) / mbar's (wave 1) piece
   // DMA: the B image = 32 pieces of 1 KB (half a k row each): wave w issues pieces 4 w .. 4 w + 3 (k rows 2 w, 2 w + 1);
   // the weights (16 x D doubles, contiguous, D <= 8) = 1 piece, requested by wave 0
   // KH = 2: each image = 16 pieces (8 k rows): wave w requests row w of both
@@ -204,8 +214,8 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
         // rows 16 kt .. 16 kt + 15 of s: 16 D doubles from s + 16 kt D; reads past the end of s return zeros (num_records)
         const long off = kt * 16 * g.D * 8, left = g.P * g.D * 8 - off;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(reinterpret_cast<const char*>(g.s) + off), 0, (int)(left > 0x7ffffff0 ? 0x7ffffff0 : (left > 0 ? left : 0)), 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, W_LDS3(base + GR_STAGE_B), 16, (unsigned)(lane * 16), 0, 0, 0);
+            const_cast<char*>(reinterpret_cast<const char*>(W == 0 ? g.s : g.mb) + off), 0, (int)(left > 0x7ffffff0 ? 0x7ffffff0 : (left > 0 ? left : 0)), 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, W_LDS3(base + GR_STAGE_B + (W == 0 ? 0 : 1024)), 16, (unsigned)(lane * 16), 0, 0, 0);
       }
     }
   };
@@ -224,6 +234,7 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
   double fb[4][4];              // ring of four units: [slot][e]
   double fr[NRM], fa[NRM];      // A fragments of a group: raw (read one phase ahead) and scaled
   double fw = 1.0;
+  double fm = 0.0, dacc[2][4];  // DUW: mbar[k][d] of the phase, the du partial sums of the wave's row blocks (k = 2 lk + q mod 8 only)
 
   auto readB = [&](int slot, unsigned off) __attribute__((always_inline)) {
     const d2_t v0 = *reinterpret_cast<const d2_t*>(smem + bB0 + off);
@@ -249,6 +260,12 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
     for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[b][e] = 0.0;
+    if constexpr (DUW) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) dacc[q][ri] = 0.0;
+    }
     unsigned wbase = (unsigned)(GR_STAGE_B + (2 * lk * g.D + d) * 8);
     const unsigned wstep = (unsigned)(g.D * 8);
     // raw A fragments (and the weight) of phase ph = substep * NG + group
@@ -258,6 +275,7 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
 #pragma unroll
       for (int ri = 0; ri < GM::m.nr[q]; ++ri) fr[ri] = *reinterpret_cast<const double*>(smem + bA + (ko + GM::m.rows[q][ri] * 128));
       if constexpr (SC) fw = *reinterpret_cast<const double*>(smem + wbase + (unsigned)(8 * (sub >> 1) + (sub & 1)) * wstep);
+      if constexpr (DUW) fm = *reinterpret_cast<const double*>(smem + wbase + 1024u + (unsigned)(8 * (sub >> 1) + (sub & 1)) * wstep);
     };
 
     // ---- prologue: three k-tiles requested, the first one landed and published
@@ -303,6 +321,10 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
         if constexpr (ph_start) {
 #pragma unroll
           for (int ri = 0; ri < GM::m.nr[q]; ++ri) fa[ri] = SC ? fr[ri] * fw : fr[ri];
+          if constexpr (DUW) {
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) dacc[q][ri] += fr[ri] * fm;
+          }
           // raw fragments of the next phase; the k-tile's last phase reads those of the NEXT k-tile's first one (its
           // stage was published by this k-tile's barrier)
           if constexpr ((ph + 1) % (SUBH * NG) != 0) {
@@ -389,26 +411,38 @@ __device__ __forceinline__ void gram_wave(const GramArgs& g, char* smem, int wav
         }
       });
     });
+    if constexpr (DUW) {
+      // du partial of column m = 16 r + li: the four lk groups hold the k = 2 lk + q (mod 8) shares
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+          double v = dacc[q][ri];
+          v += __shfl_xor(v, 16);
+          v += __shfl_xor(v, 32);
+          if (lk == 0) slot[136 * 256 - lane * 4 + 16 * GM::m.rows[q][ri] + li] = v;
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
 }
 
-template <bool SC, int KH>
+template <bool SC, int KH, bool DU = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_gram_kernel(GramArgs g) {
   __shared__ __attribute__((aligned(1024))) char smem[GR_NSTAGE * GR_STAGE];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   switch (wave) {
-    case 0: gram_wave<0, SC, KH>(g, smem, wave, lane); break;
-    case 1: gram_wave<1, SC, KH>(g, smem, wave, lane); break;
-    case 2: gram_wave<2, SC, KH>(g, smem, wave, lane); break;
-    case 3: gram_wave<3, SC, KH>(g, smem, wave, lane); break;
-    case 4: gram_wave<4, SC, KH>(g, smem, wave, lane); break;
-    case 5: gram_wave<5, SC, KH>(g, smem, wave, lane); break;
-    case 6: gram_wave<6, SC, KH>(g, smem, wave, lane); break;
-    default: gram_wave<7, SC, KH>(g, smem, wave, lane); break;
+    case 0: gram_wave<0, SC, KH, DU>(g, smem, wave, lane); break;
+    case 1: gram_wave<1, SC, KH, DU>(g, smem, wave, lane); break;
+    case 2: gram_wave<2, SC, KH, DU>(g, smem, wave, lane); break;
+    case 3: gram_wave<3, SC, KH, DU>(g, smem, wave, lane); break;
+    case 4: gram_wave<4, SC, KH, DU>(g, smem, wave, lane); break;
+    case 5: gram_wave<5, SC, KH, DU>(g, smem, wave, lane); break;
+    case 6: gram_wave<6, SC, KH, DU>(g, smem, wave, lane); break;
+    default: gram_wave<7, SC, KH, DU>(g, smem, wave, lane); break;
   }
 }
 

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramArgs g, GramReduce
     for (; i < i1; ++i) s0 += w[((long)x + 8 * i) * 2 * GR_SLOT_DOUBLES];
   }
   const double sum = (s0 + s1) + (s2 + s3);
+  if (id == 136) { g.du[(long)t * g.D + d] += sum; return; }      // (the du block: thread = column of Ct)
   int r = 0;
   while ((r + 1) * (r + 2) / 2 <= id) ++r;
   const int c = id - r * (r + 1) / 2;
@@ -90,6 +91,8 @@ bool gemm_gram_ok(const GemmArgs& a) {
   if (a.ascale_mode == 2) { if (a.ascale == nullptr || a.as_ld != a.batch) return false; }
   else if (a.ascale_mode != 0 || a.batch != 1) return false;
   if (a.A != a.B && (a.ascale_mode != 0 || a.batch != 1)) return false;                  // two sources: unweighted, one output
+  if ((a.gram_mb != nullptr) != (a.gram_du != nullptr)) return false;
+  if (a.gram_mb && (a.ascale_mode != 2 || (reinterpret_cast<uintptr_t>(a.gram_mb) & 15u))) return false;   // du rides on the weighted form
   if (a.epi != 0 || a.rank != 0 || a.eadd != nullptr || a.C2 != nullptr || a.a_blocked || a.c_blocked || a.tri_row0 != 0) return false;
   if ((reinterpret_cast<uintptr_t>(a.A) & 15u) || (reinterpret_cast<uintptr_t>(a.B) & 15u) || (reinterpret_cast<uintptr_t>(a.C) & 7u)) return false;
   if (a.ascale && (reinterpret_cast<uintptr_t>(a.ascale) & 15u)) return false;
@@ -108,11 +111,14 @@ hipError_t gemm_gram(hipStream_t st, const GemmArgs& a) {
   g.ws = a.gram_ws;
   g.P = a.K;
   g.D = a.batch;
+  g.mb = a.gram_mb;
+  g.du = a.gram_du;
   const unsigned grid = (unsigned)gemm_persistent_grid(a, gram_grid(a.cu_count));          // (K >= min_k: every workgroup has k-tiles; the scratch is sized for the full grid)
   if (g.A) hipLaunchKernelGGL((gemm_gram_kernel<false, 2>), dim3(grid), dim3(512), 0, st, g);
+  else if (g.s && g.mb) hipLaunchKernelGGL((gemm_gram_kernel<true, 1, true>), dim3(grid), dim3(512), 0, st, g);
   else if (g.s) hipLaunchKernelGGL((gemm_gram_kernel<true, 1>), dim3(grid), dim3(512), 0, st, g);
   else hipLaunchKernelGGL((gemm_gram_kernel<false, 1>), dim3(grid), dim3(512), 0, st, g);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(136, g.D), dim3(256), 0, st, g, gram_reduce_map(g.P, g.D, (int)grid));
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(g.mb ? 137 : 136, g.D), dim3(256), 0, st, g, gram_reduce_map(g.P, g.D, (int)grid));
   return hipGetLastError();
 }
 

@@ -128,8 +128,8 @@ def load():
         "dgp_prof_mark": (C.c_int, [vp]),
         "dgp_prof_marks_read": (C.c_int, [vp, i32, _dp, C.POINTER(i32)]),
         "dgp_dev_gemm": (C.c_int, [vp, i32, i64, i64, i64, _dp, i64, _dp, i64, _dp, i64, dbl, i32, i32, i32, i64, i32, _dp]),
-        "dgp_dev_gram": (C.c_int, [vp, _dp, _dp, i64, i32, _dp]),
-        "dgp_dev_layer_products": (C.c_int, [vp, i64, i32, i32] + [_dp] * 14 + [C.POINTER(i32)]),
+        "dgp_dev_gram": (C.c_int, [vp, _dp, _dp, i64, i32, _dp, _dp, _dp]),
+        "dgp_dev_layer_products": (C.c_int, [vp, i64, i32, i32] + [_dp] * 15 + [C.POINTER(i32)]),
         "dgp_dev_chol": (C.c_int, [vp, _dp, i32, i32]),
         "dgp_dev_trinv": (C.c_int, [vp, _dp, _dp, i32, i32]),
         "dgp_dev_normals": (C.c_int, [vp, u64, i32, i32, i64, i64, i32, _dp]),
@@ -467,30 +467,37 @@ class Context:
                                          alpha, beta, splits, tri, triblk, repeats, C.byref(ms)))
         return (Cm, ms.value) if repeats else Cm
 
-    def dev_gram(self, Cmat, s=None, G0=None):
-        """G[d] (+)= sum_p s[p, d] c_p c_p^T (lower triangles) by the library's dispatcher: Cmat [P, 256], s [P, D] or None."""
+    def dev_gram(self, Cmat, s=None, G0=None, mb=None, du0=None):
+        """G[d] (+)= sum_p s[p, d] c_p c_p^T (lower triangles) by the library's dispatcher: Cmat [P, 256], s [P, D] or None.
+        With mb [P, D]: also du (+)= Cmat^T mb, inside the same launch where the Gram kernel runs it; returns (G, du)."""
         Cmat = _c(Cmat)
         D = 1 if s is None else s.shape[1]
         G = np.zeros((D, 256, 256)) if G0 is None else _c(G0).copy()
         sp = None if s is None else _c(s)
-        self._chk(self._lib.dgp_dev_gram(self._h, _ptr(Cmat), None if sp is None else _ptr(sp), Cmat.shape[0], D, _ptr(G)))
-        return G
+        if mb is None:
+            self._chk(self._lib.dgp_dev_gram(self._h, _ptr(Cmat), None if sp is None else _ptr(sp), Cmat.shape[0], D, _ptr(G), None, None))
+            return G
+        mbp = _c(mb)
+        du = np.zeros((256, D)) if du0 is None else _c(du0).copy()
+        self._chk(self._lib.dgp_dev_gram(self._h, _ptr(Cmat), _ptr(sp), Cmat.shape[0], D, _ptr(G), _ptr(mbp), _ptr(du)))
+        return G, du
 
     ENGINES = {0: "engine128x64", 1: "wide", 2: "tall", 3: "tallu", 4: "gram", 5: "small"}
 
     def dev_layer_products(self, Kt, Linv, Wcat, u, vbar, mbar):
         """The point contractions of one SVGP layer (dgp_dev_layer_products) on explicit operands: Kt [P, Mp], Linv [Mp, Mp]
-        lower, Wcat [Mp, D*Mp], u [Mp, D], vbar / mbar [P, D].  Returns a dict of Ct, cn, T, tn, mean0, Cbar, g, du and
-        `engines`: the kernel family that ran (Ct, T, Cbar, g, du)."""
+        lower, Wcat [Mp, D*Mp], u [Mp, D], vbar / mbar [P, D].  Returns a dict of Ct, cn, T, tn, mean0, Cbar, g, du, Gd (lower
+        triangles of [D, Mp, Mp]) and `engines`: the kernel family that ran (Ct, T, Cbar, g, du, Gd)."""
         Kt, Linv, Wcat, u, vbar, mbar = (_c(a) for a in (Kt, Linv, Wcat, u, vbar, mbar))
         P, Mp = Kt.shape
         D = u.shape[1]
         assert Linv.shape == (Mp, Mp) and Wcat.shape == (Mp, D * Mp) and vbar.shape == (P, D) and mbar.shape == (P, D)
         out = {"Ct": np.empty((P, Mp)), "cn": np.empty(P), "T": np.empty((P, D * Mp)), "tn": np.empty((P, D)),
-               "mean0": np.empty((P, D)), "Cbar": np.empty((P, Mp)), "g": np.empty((P, Mp)), "du": np.empty((Mp, D))}
-        eng = (C.c_int32 * 5)()
+               "mean0": np.empty((P, D)), "Cbar": np.empty((P, Mp)), "g": np.empty((P, Mp)), "du": np.empty((Mp, D)),
+               "Gd": np.empty((D, Mp, Mp))}
+        eng = (C.c_int32 * 6)()
         self._chk(self._lib.dgp_dev_layer_products(self._h, P, Mp, D, _ptr(Kt), _ptr(Linv), _ptr(Wcat), _ptr(u), _ptr(vbar),
-                                                   _ptr(mbar), *[_ptr(out[k]) for k in ("Ct", "cn", "T", "tn", "mean0", "Cbar", "g", "du")],
+                                                   _ptr(mbar), *[_ptr(out[k]) for k in ("Ct", "cn", "T", "tn", "mean0", "Cbar", "g", "du", "Gd")],
                                                    eng))
         out["engines"] = [self.ENGINES[int(e)] for e in eng]
         return out

@@ -224,22 +224,25 @@ int dgp_dev_gemm(dgp_ctx* ctx, int32_t op /*0 NN,1 NT,2 TN*/, int64_t M, int64_t
                  int32_t splits, int32_t tri, int64_t triblk, int32_t repeats, double* ms_per_call);
 /* G[d] += sum_p s[p][d] c_p c_p^T (lower triangles; s == NULL: weights 1, D = 1) through the library's dispatcher, i.e.
  * the weighted Gram kernel when eligible (Mp = 256, P a multiple of 16 >= 8192, D <= 8), else the 128 x 64 engine:
- * the reduction  G_d = sum_p vbar_pd c_p c_p^T  of SURVEY App. C step 2 on its own. */
+ * the reduction  G_d = sum_p vbar_pd c_p c_p^T  of SURVEY App. C step 2 on its own.  With mb / du (both or neither; needs
+ * s): also du[m][d] += sum_p mb[p][d] C[p][m] (the adjoint of mean = c^T u_d, App. C step 1), inside the same launch when the
+ * Gram kernel runs it, as in the backward pass. */
 int dgp_dev_gram(dgp_ctx* ctx, const double* C /* [P,256] */, const double* s /* [P,D] or NULL */, int64_t P, int32_t D,
-                 double* G /* [D,256,256], in/out */);
+                 double* G /* [D,256,256], in/out */, const double* mb /* [P,D] or NULL */, double* du /* [256,D] in/out, or NULL */);
 /* The point contractions of ONE SVGP layer on caller-supplied operands, issued through the same argument builders as the
- * forward / backward pass (csrc/dgp_ctx.h: args_Ct, args_T, args_mean0, args_Cbar, args_g, args_du), so that a size selects the
+ * forward / backward pass (csrc/dgp_ctx.h: args_Ct, args_T, args_mean0, args_Cbar, args_g, args_du, args_G), so that a size selects the
  * kernel it selects in training (128 x 64 engine, wide-tile, tall-tile): layers.py:243-263 in whitened form and its
  * adjoint.  Mp a multiple of 64, Linv lower triangular, Wcat = [W_0 | ... | W_{D-1}], W_d lower.
  *   Ct   = Kt Linv^T                                  cn[p]    = |c_p|^2
  *   T_d  = Ct W_d   (returned row-major [P, D*Mp])    tn[p][d] = |t_pd|^2        mean0 = Ct u
  *   Cbar = sum_d 2 vbar_pd (T_d W_d^T - Ct) + mbar u^T
  *   g    = (Cbar Linv) .* Kt                          du = Ct^T mbar
- * engines[5] (may be NULL): the kernel family (gemm_engine_of) that ran Ct, T, Cbar, g, du.                          */
+ *   Gd[d] = sum_p vbar_pd c_p c_p^T  (lower triangle of [D, Mp, Mp]; with Mp = 256 and enough points du rides on this launch)
+ * engines[6] (may be NULL): the kernel family (gemm_engine_of) that ran Ct, T, Cbar, g, du, Gd.                      */
 int dgp_dev_layer_products(dgp_ctx* ctx, int64_t P, int32_t Mp, int32_t D, const double* Kt, const double* Linv,
                            const double* Wcat, const double* u, const double* vbar, const double* mbar, double* Ct,
                            double* cn, double* T, double* tn, double* mean0, double* Cbar, double* g, double* du,
-                           int32_t* engines);
+                           double* Gd, int32_t* engines);
 int dgp_dev_chol(dgp_ctx* ctx, double* A, int32_t M, int32_t batch);            /* in place, lower */
 int dgp_dev_trinv(dgp_ctx* ctx, const double* L, double* X, int32_t M, int32_t batch);
 int dgp_dev_normals(dgp_ctx* ctx, uint64_t seed, int32_t layer, int32_t S, int64_t n0, int64_t N, int32_t D,

@@ -3,7 +3,8 @@ forward_chunk / backward_chunk on explicit operands) against NumPy.
 
 Reference arithmetic being checked (whitened form of R/dgp_dace/utils/layers.py:243-263 and its adjoint):
     Ct = Kt Linv^T, |c|^2, T_d = Ct W_d, |t_d|^2, mean0 = Ct u,
-    Cbar = sum_d 2 vbar_d (T_d W_d^T - Ct) + mbar u^T,  g = (Cbar Linv) .* Kt,  du = Ct^T mbar.
+    Cbar = sum_d 2 vbar_d (T_d W_d^T - Ct) + mbar u^T,  g = (Cbar Linv) .* Kt,  du = Ct^T mbar,
+    G_d = tril(Ct^T diag(vbar_d) Ct)  (du rides on G_d's launch where the Gram kernel runs it: gemm_gram.h, form DU).
 
 Used in-process by tests/test_gpu_units.py and as a child process (the kernel switches DGP_TALL / DGP_TALLU / DGP_WIDE are
 read once per process):  python tests/layer_products_check.py P:Mp:D:engCt,engT,engCbar [...]
@@ -38,20 +39,22 @@ def reference(Kt, Linv, Wcat, u, vbar, mbar):
         Cbar += 2.0 * vbar[:, d:d + 1] * (Td @ Wcat[:, d * Mp:(d + 1) * Mp].T)
     return {"Ct": Ct, "cn": (Ct * Ct).sum(axis=1), "T": T,
             "tn": (T.reshape(P, D, Mp) ** 2).sum(axis=2), "mean0": Ct @ u, "Cbar": Cbar,
-            "g": (Cbar @ Linv) * Kt, "du": Ct.T @ mbar}
+            "g": (Cbar @ Linv) * Kt, "du": Ct.T @ mbar,
+            "Gd": np.stack([np.tril(Ct.T @ (vbar[:, d:d + 1] * Ct)) for d in range(D)])}
 
 
 def check(ctx, P, Mp, D, expect=None, seed=None):
     """Runs the layer's products at [P, Mp] with D outputs; compares every element of every output with NumPy; asserts the
-    kernel families that ran (Ct, T, Cbar) when `expect` is given.  Returns the engines."""
+    kernel families that ran - (Ct, T, Cbar) or (Ct, T, Cbar, du, Gd) - when `expect` is given.  Returns the engines."""
     ops = operands(P, Mp, D, P + 31 * D + Mp if seed is None else seed)
     got = ctx.dev_layer_products(*ops)
     if expect is not None:
-        assert got["engines"][:3] == list(expect), (P, Mp, D, got["engines"])
+        ran = got["engines"][:3] + (got["engines"][4:6] if len(expect) == 5 else [])
+        assert ran == list(expect), (P, Mp, D, got["engines"])
     ref = reference(*ops)
     for k, r in ref.items():
         scale = np.abs(r).max()
-        err = np.abs(got[k] - r)
+        err = np.abs((np.tril(got[k]) if k == "Gd" else got[k]) - r)
         i = np.unravel_index(np.argmax(err), err.shape)
         assert err.max() <= TOL * scale, (k, P, Mp, D, got["engines"], "worst element", i, float(err.max()), float(scale))
     return got["engines"]

@@ -101,9 +101,9 @@ def test_weighted_gram_kernel_against_numpy(ctx, P, D):
 # 128 x 256 on (csrc/gemm_wide.hip): `Ct` and `dC` (256 columns) from 98 304 rows, `T` from 98 304 / D rows; the tall-tile
 # kernels (Mp = 256) replace its `T` / `dC` modes.  98 432 = 769 x 128 rows: the last 256-row tile is half empty.
 PRODUCTION_CASES = [
-    (98304 + 128, 256, 8, ("wide", "tall", "tallu")),
-    (98304, 256, 1, ("wide", "tall", "tallu")),
-    (98304 + 384, 256, 3, ("wide", "tall", "tallu")),
+    (98304 + 128, 256, 8, ("wide", "tall", "tallu", "gram", "gram")),        # (du rides on G_d's Gram launch)
+    (98304, 256, 1, ("wide", "tall", "tallu", "gram", "gram")),
+    (98304 + 384, 256, 3, ("wide", "tall", "tallu", "gram", "gram")),
     (49152 + 128, 512, 2, ("wide", "wide", "wide")),          # BASELINE config 4's inducing count
     (20000, 256, 8, ("engine128x64", "engine128x64", "engine128x64")),   # below the limits: the 128 x 64 engine, padded rows
     (3001, 192, 2, ("engine128x64", "engine128x64", "engine128x64")),
@@ -113,7 +113,7 @@ PRODUCTION_CASES = [
 @pytest.mark.parametrize("P,Mp,D,expect", PRODUCTION_CASES)
 def test_layer_products_on_the_production_kernels_against_numpy(ctx, P, Mp, D, expect):
     """Every element of Ct (+ |c|^2), T (blocked output, + |t_d|^2), mean0, dC (scaled A, the `- c` epilogue term, the
-    rank-D term mbar u^T), g = (dC Linv) .* Kt and du against NumPy, through the launches forward_chunk / backward_chunk
+    rank-D term mbar u^T), g = (dC Linv) .* Kt, du and G_d (du inside G_d's Gram launch where that kernel runs) against NumPy, through the launches forward_chunk / backward_chunk
     make (dgp_dev_layer_products), at row counts where the headline configuration's kernels are the ones selected -
     asserted, not assumed.  Reference: R/dgp_dace/utils/layers.py:243-263 (whitened) and its adjoint."""
     from layer_products_check import check
@@ -125,7 +125,7 @@ def test_layer_products_on_the_wide_tile_kernel_modes_against_numpy():
     A, `- c`, rank term) then run as modes of the wide-tile kernel.  The switches are read once per process: child process."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
-    specs = [f"{P}:{Mp}:{D}:wide,wide,wide" for P, Mp, D, e in PRODUCTION_CASES[:3]]
+    specs = [f"{P}:{Mp}:{D}:wide,wide,wide,gram,gram" for P, Mp, D, e in PRODUCTION_CASES[:3]]
     env = dict(os.environ, DGP_TALL="0", DGP_TALLU="0")
     p = subprocess.run([sys.executable, os.path.join(here, "layer_products_check.py")] + specs, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=1200)
