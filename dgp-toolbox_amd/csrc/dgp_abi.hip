@@ -187,6 +187,7 @@ int dgp_model_set(dgp_ctx* ctx, int n_layers, const dgp_layer_desc* layers, cons
     const long MM = (long)y.Mp * y.Mp;
     const int D = y.d.D_out;
     RET(dev_alloc(ctx, &y.Kuu, MM)); RET(dev_alloc(ctx, &y.Lu, MM)); RET(dev_alloc(ctx, &y.Linv, MM)); RET(dev_alloc(ctx, &y.LinvT, MM));
+    if (y.Mp == 256 && y.d.D_out <= 8) RET(dev_alloc(ctx, &y.alpha, (size_t)y.Mp * y.d.D_out));
     if (y.Mp == 256 && !ctx->gram_ws) RET(dev_alloc(ctx, &ctx->gram_ws, gemm_gram_ws_bytes(ctx->cu_count) / 8));
     RET(dev_alloc(ctx, &y.Lq, MM * D)); RET(dev_alloc(ctx, &y.qmu_p, (long)y.Mp * D));
     RET(dev_alloc(ctx, &y.Wcat, MM * D)); RET(dev_alloc(ctx, &y.u, (long)y.Mp * D)); RET(dev_alloc(ctx, &y.Scat, MM * D)); RET(dev_alloc(ctx, &y.Z1, (long)y.Mp * (y.d.D_in + 1)));
@@ -1197,7 +1198,8 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, cons
     return DGP_OK;
   };
   struct Free { std::vector<double*>& b; ~Free() { for (double* q : b) (void)hipFree(q); } } freer{bufs};
-  double *dKt, *dLinv, *dLinvT, *dW, *dS, *du_, *dvb, *dmb, *dCt, *cnp, *tnp, *dT, *dm0, *dCb, *dKb, *dG, *ddu, *dGd;
+  double *dKt, *dLinv, *dLinvT, *dW, *dS, *du_, *dvb, *dmb, *dCt, *cnp, *tnp, *dT, *dm0, *dCb, *dKb, *dG, *ddu, *dGd, *dal;
+  RET(take(&dal, (size_t)Mp * D, true));
   if (Mp == 256 && !ctx->gram_ws) RET(dev_alloc(ctx, &ctx->gram_ws, gemm_gram_ws_bytes(ctx->cu_count) / 8));
   RET(take(&dGd, (size_t)D * MM, true));
   RET(take(&dKt, (size_t)Pm * Mp, true)); RET(take(&dLinv, MM, false)); RET(take(&dLinvT, MM, false));
@@ -1215,12 +1217,15 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, cons
   HIPCHK(wcat_transpose(ctx->st, dLinv, Mp, 1, dLinvT));         // as prep() does
   HIPCHK(wcat_transpose(ctx->st, dW, Mp, D, dS));                // Scat = W_d^T stacked (stored-T form)
   // forward (forward_chunk)
-  GemmArgs aC = args_Ct(Pm, Mp, dKt, dLinvT, dCt, cnp);
+  const bool with_alpha = Mp == 256 && D <= 8;          // as dgp_set_layers allocates it
+  if (with_alpha) RET(G(ctx, 2, GEMM_NN, Mp, D, Mp, dLinvT, Mp, du_, D, dal, D, 1.0, 0));      // alpha = LinvT u, as prep() does
+  GemmArgs aC = args_Ct(Pm, Mp, dKt, dLinvT, dCt, cnp, with_alpha ? dal : nullptr, dm0, D);
   GemmArgs aT = args_T(Pm, Mp, D, dCt, dW, dT, tnp, ctx->blocked_t);
   const bool wide = gemm_wide_ok(aC) && gemm_wide_ok(aT);
   int nplane = 0;
-  RET(launch_Ct_T(ctx, aC, aT, dLinv, P, &nplane));
-  RET(GX(ctx, 0, GEMM_NN, args_mean0(Pm, Mp, D, dCt, du_, dm0)));
+  bool mean_done = false;
+  RET(launch_Ct_T(ctx, aC, aT, dLinv, P, &nplane, &mean_done));
+  if (!mean_done) RET(GX(ctx, 0, GEMM_NN, args_mean0(Pm, Mp, D, dCt, du_, dm0)));
   // backward (backward_chunk, stored-T form)
   GemmArgs aB = args_Cbar(Pm, Mp, D, dT, dS, dCb, dvb, dCt, dmb, du_, ctx->blocked_t);
   RET(GX(ctx, 0, GEMM_NN, aB));
@@ -1241,6 +1246,7 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, cons
     engines[2] = gemm_engine_of(GEMM_NN, aB);
     engines[3] = gemm_engine_of(GEMM_NN, aG);
     engines[5] = gemm_engine_of(GEMM_TN, aGd);
+    engines[6] = mean_done ? 1 : 0;
     engines[4] = du_in_gram ? engines[5] : gemm_engine_of(GEMM_TN, aU);
   }
   // results: row-norm planes summed as finalize_layer sums them, T taken out of the engine's blocked layout

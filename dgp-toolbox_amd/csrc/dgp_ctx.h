@@ -42,6 +42,7 @@ struct Layer {
   double *meanW = nullptr, *meanb = nullptr;
   double *Kuu, *Lu, *Linv, *Lq, *qmu_p, *Wcat, *u;   // derived small matrices (padded to Mp)
   double *LinvT = nullptr;                           // Linv^T: the B operand of c = Lu^-1 k as an NN product (wide-tile kernel)
+  double *alpha = nullptr;                           // LinvT u [Mp x D] (Mp = 256, D <= 8): mean0 = Kt alpha inside the Ct launch (gemm_wide.h, mode 4)
   double *Scat;                                      // [D*Mp x Mp] (backward only): W_d^T stacked when t_d is kept from the
                                                      // forward pass (ctx->store_t), else S'_d = W_d W_d^T - I stacked
   double *Tt = nullptr;                              // [points][D*Mp]: t_d = W_d^T c (training chunks, ctx->store_t)
@@ -397,7 +398,7 @@ void free_model(dgp_ctx* ctx) {
   ctx->ws_key_N = -1;
   ctx->prep_level = 0;
   for (auto& l : ctx->L) {
-    dev_free(l.Kuu); dev_free(l.Lu); dev_free(l.Linv); dev_free(l.LinvT); dev_free(l.Lq); dev_free(l.qmu_p); dev_free(l.Wcat);
+    dev_free(l.Kuu); dev_free(l.Lu); dev_free(l.Linv); dev_free(l.LinvT); dev_free(l.alpha); dev_free(l.Lq); dev_free(l.qmu_p); dev_free(l.Wcat);
     dev_free(l.u); dev_free(l.Scat); dev_free(l.Z1); dev_free(l.Euu); dev_free(l.kdot); dev_free(l.dLq); dev_free(l.dqmu_p);
   }
   ctx->L.clear();
@@ -598,6 +599,7 @@ int prep_layer_launches(dgp_ctx* ctx, size_t li, bool train) {
     RET(G(ctx, 2, GEMM_NN, Mp, D, Mp, y.Linv, Mp, y.qmu_p, D, y.u, D, 1.0, 0));
   }
   HIPCHK(layer_kl(ctx->st, y.Wcat, y.u, y.Lq, y.Lu, M, Mp, D, y.d.white, ctx->scal));
+  if (y.alpha) RET(G(ctx, 2, GEMM_NN, Mp, D, Mp, y.LinvT, Mp, y.u, D, y.alpha, D, 1.0, 0));
   if (train) {
     if (ctx->store_t) {
       HIPCHK(wcat_transpose(ctx->st, y.Wcat, Mp, D, y.Scat));
@@ -729,9 +731,12 @@ ZSource zsrc_of(dgp_ctx* ctx, int l, bool use_zs, uint64_t seed, long n_goff, lo
 // tests compare element by element with NumPy at sizes where the wide-tile and tall-tile kernels are selected) issue
 // literally the same launches.
 // c = Lu^-1 k: Ct = Kt * Linv^T as an NN product with the upper-triangular LinvT, row sums |c|^2 into planes
-GemmArgs args_Ct(long Pm, int Mp, const double* Kt, const double* LinvT, double* Ct, double* cnp) {
+// with `alpha` (= LinvT u, [Mp x D]) and `mean0`: the launch may also produce mean0 = Ct u as Kt alpha (gemm_wide_mean_ok)
+GemmArgs args_Ct(long Pm, int Mp, const double* Kt, const double* LinvT, double* Ct, double* cnp, const double* alpha = nullptr,
+                 double* mean0 = nullptr, int D = 0) {
   GemmArgs a = mk(Pm, Mp, Mp, Kt, Mp, LinvT, Mp, Ct, Mp);
   a.tri = TRI_B_UPPER; a.triblk = Mp; a.epi = 2; a.rowsq = cnp; a.rowsq_ld = Pm;
+  if (alpha && mean0 && D >= 1 && D <= 8) { a.mean_alpha = alpha; a.mean_out = mean0; a.mean_d = D; }
   return a;
 }
 // t_d = W_d^T c: T = Ct * Wcat (W_d lower), row sums |t_d|^2 into planes; T itself (blocked layout) only when Tt != nullptr
@@ -783,13 +788,16 @@ GemmArgs args_du(dgp_ctx* ctx, long Pl, int Mp, int D, const double* Ct, const d
 
 // Ct then T: on the wide-tile / tall-tile kernels when BOTH apply (they share the layout of the row-norm planes: Mp/128
 // planes), else both on the 128 x 64 engine (Mp/32 planes, the triangular solve as an NT product with the lower Linv)
-int launch_Ct_T(dgp_ctx* ctx, GemmArgs aC, GemmArgs aT, const double* Linv, long Pl, int* nplane) {
+// *mean_done: the Ct launch also wrote mean0 (aC carried alpha and ran as the wide-tile kernel's mode 4)
+int launch_Ct_T(dgp_ctx* ctx, GemmArgs aC, GemmArgs aT, const double* Linv, long Pl, int* nplane, bool* mean_done) {
   const long Mp = aC.N, D = aT.N / Mp;
   const double tri1 = (double)Pl * Mp * (Mp + 1.0);
+  aC.cu_count = ctx->cu_count; aT.cu_count = ctx->cu_count;
   const bool wide = gemm_wide_ok(aC) && gemm_wide_ok(aT);
   *nplane = wide ? (int)(Mp / 128) : (int)(Mp / 32);
+  *mean_done = wide && gemm_wide_mean_ok(aC);
   if (wide) {
-    RET(GX(ctx, 0, GEMM_NN, aC, tri1, (double)Pl * Mp * 16));
+    RET(GX(ctx, 0, GEMM_NN, aC, tri1 + (*mean_done ? 2.0 * Pl * Mp * D : 0.0), (double)Pl * Mp * 16));
   } else {
     aC.B = Linv; aC.no_wide = 1; aT.no_wide = 1;
     RET(GX(ctx, 0, GEMM_NT, aC, tri1, (double)Pl * Mp * 16));
@@ -816,7 +824,7 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
     // c = Lu^-1 k (|c|^2 partials) and t_d = W_d^T c (|t_d|^2 partials always leave the kernel; t_d itself only for
     // the backward pass, store_t).  Both run on the wide-tile kernel (gemm_wide.h: 2 partial planes per 256 columns)
     // when it applies, else on the 128 x 64 engine (Mp/32 planes, the triangular solve as an NT product).
-    GemmArgs aC = args_Ct(Pm, Mp, y.Kt, y.LinvT, y.Ct, y.cnp);
+    GemmArgs aC = args_Ct(Pm, Mp, y.Kt, y.LinvT, y.Ct, y.cnp, y.alpha, y.mean0, D);
     GemmArgs aT = args_T(Pm, Mp, D, y.Ct, y.Wcat, y.Tt, y.tnp, ctx->blocked_t);
     int nplane = 0;
     if (small_fused(ctx, y)) {
@@ -834,8 +842,9 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
           HIPCHK(rbf_kuf(ctx->st, y.d.kernel_kind, Xin, Pl, row0, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, Mp, Din,
                          y.Kt, y.Et));
       }
-      RET(launch_Ct_T(ctx, aC, aT, y.Linv, Pl, &nplane));
-      RET(GX(ctx, 0, GEMM_NN, args_mean0(Pm, Mp, D, y.Ct, y.u, y.mean0), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
+      bool mean_done = false;
+      RET(launch_Ct_T(ctx, aC, aT, y.Linv, Pl, &nplane, &mean_done));
+      if (!mean_done) RET(GX(ctx, 0, GEMM_NN, args_mean0(Pm, Mp, D, y.Ct, y.u, y.mean0), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
     }
     {
       ProfScope ps(ctx, 1, 0, (double)Pl * nplane * 8 * (1 + D));

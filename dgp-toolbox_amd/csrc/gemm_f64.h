@@ -108,6 +108,12 @@ struct GemmArgs {
   // itself - when the launch does not go to the Gram kernel (gemm_engine_of(...) != 4).
   const double* gram_mb = nullptr;
   double* gram_du = nullptr;
+  // the forward product Ct = Kt LinvT on the wide-tile kernel only (gemm_wide.h, mode 4): also mean_out[m][d] = sum_k A[m][k]
+  // mean_alpha[k][d] (d < mean_d <= 8; alpha = LinvT u, so that this is mean0 = Ct u).  Ignored - the caller issues that product
+  // itself - unless gemm_wide_mean_ok(a).
+  const double* mean_alpha = nullptr;
+  double* mean_out = nullptr;
+  int mean_d = 0;
   int no_wide = 0;     // 1: keep this product on the 128 x 64 engine even where the wide-tile kernel (gemm_wide.h) applies
   // the device this launch is for, as its context knows it (0: ask the runtime for the current device's CU count), and the
   // CUs a persistent one-workgroup-per-CU kernel (wide-tile, tall-tile, Gram) leaves free for a collective that runs beside

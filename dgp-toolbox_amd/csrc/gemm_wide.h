@@ -65,12 +65,20 @@ struct WCur {
 //   1 = alpha 1, row sums of squares + C (row-major or blocked); 2 = alpha 1, C and C2 = C .* emul; 3 = alpha 1, row
 //   sums of squares only.  Modes 1-3 write one block column at a time, interleaved with the k-tile stream (the products
 //   with one k block per tile: an epilogue every 16 k-tiles), through buffer stores with per-lane offsets computed once.
+//   4 = mode 1 of the forward product Ct = Kt LinvT (DIR 1, N = K = triblk = 256) that ALSO produces the layer's mean
+//   before the mean function, mean0 = Ct u (layers.py:249, whitened), as Kt alpha with alpha = LinvT u [256 x D <= 8]
+//   (prepared with the layer's matrices): alpha sits in the 16 KB of LDS the ring leaves free, every k-substep gets two more
+//   MFMAs (the A fragments of the wave's two row blocks times alpha's k rows; wave column wc owns outputs 4 wc .. 4 wc + 3):
+//   128 MFMAs per tile next to 2304, instead of a launch of its own that read Ct once more (2 GB per 10^6 points).
 // Host-guaranteed (gemm_wide_ok): A not transposed, B not transposed, M % 128 == 0, N % 256 == 0, K % 16 == 0,
 // triblk % 256 == 0, K % min(K, triblk) == 0, batch == splits == 1, beta == 0, 16-byte aligned operands.
 template <int DIR, bool SCALED, int EM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_wide_kernel(GemmArgs g) {
-  constexpr int LDS_BYTES = W_NSTAGE * W_STAGE + (SCALED ? WBM * W_MAXD * 8 : 0);
+  constexpr int LDS_BYTES = W_NSTAGE * W_STAGE + ((SCALED || EM == 4) ? WBM * W_MAXD * 8 : 0);
+  static_assert(EM != 4 || (DIR == 1 && !SCALED), "mode 4 is the forward product Ct = Kt LinvT");
+  constexpr bool E_RS = EM == 1 || EM == 3 || EM == 4;      // row sums of squares
+  constexpr bool E_ST = EM == 1 || EM == 2 || EM == 4;      // C is stored
   __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -176,6 +184,16 @@ void gemm_wide_kernel(GemmArgs g) {
   double fa[2][2][2];       // [s8][q][i]
   double fb[4][4];          // ring of four units: [slot][e]
   double sc[2] = {1.0, 1.0};
+  // mode 4: alpha's k row of the next k-substep (ONE value, read a substep ahead of its MFMAs: the kernel has no registers
+  // to spare), the mean accumulators: macc[i] of lane (li, lk) is mean0[m0 + (2 wr + i) 16 + 4 (li >> 2) + lk][4 wc + (li & 3)]
+  double fm = 0.0, macc[2] = {0.0, 0.0};
+  auto read_fm = [&](auto tc, auto sc_) __attribute__((always_inline)) {       // alpha[16 t + 8 s8 + 2 lk + q][4 wc + (li & 3)]
+    constexpr int t = decltype(tc)::value, sub = decltype(sc_)::value;
+    int l2 = lane;
+    asm volatile("" : "+v"(l2));          // (the address is re-derived at every use instead of living in a register)
+    const unsigned amean = (unsigned)(W_NSTAGE * W_STAGE + ((2 * (l2 >> 4)) * 8 + 4 * wc + (l2 & 3)) * 8);
+    fm = *reinterpret_cast<const double*>(smem + amean + (unsigned)((16 * t + 8 * (sub >> 1) + (sub & 1)) * 64));
+  };
 
   auto readA = [&](int s8) __attribute__((always_inline)) {
 #pragma unroll
@@ -234,6 +252,14 @@ void gemm_wide_kernel(GemmArgs g) {
   // has to allow for, st_b = those the wait after it has to (a lower bound is safe: it only waits longer).
   int st_a = 0, st_b = 0;
 
+  if constexpr (EM == 4) {        // alpha [256][D] -> LDS [256][8], zero-padded (published by the prologue's barrier)
+    double* al = reinterpret_cast<double*>(smem + W_NSTAGE * W_STAGE);
+    for (int x = tid; x < 256 * 8; x += 512) {
+      const int d = x & 7;
+      al[x] = d < g.mean_d ? g.mean_alpha[(x >> 3) * g.mean_d + d] : 0.0;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
   // ---- prologue: three k-tiles in flight, the first one landed and published, its first fragments requested ----
   issue(load, 0); advance(load);
   issue(load, 1); advance(load);
@@ -247,6 +273,9 @@ void gemm_wide_kernel(GemmArgs g) {
     readA(0);
     readB(0, o0);
     readB(1, o1);
+  }
+  if constexpr (EM == 4) {
+    read_fm(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
   }
 
   using std::integral_constant;
@@ -291,7 +320,7 @@ void gemm_wide_kernel(GemmArgs g) {
   };
   auto epi_fast = [&](auto jc, unsigned tm, unsigned tn, bool last_block, bool after_dma) __attribute__((always_inline)) {
     constexpr int j = decltype(jc)::value;
-    if constexpr (EM == 1 || EM == 3) {
+    if constexpr (E_RS) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -310,7 +339,7 @@ void gemm_wide_kernel(GemmArgs g) {
         }
       }
     }
-    if constexpr (EM == 1 || EM == 2) {
+    if constexpr (E_ST) {
       const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(tile_base(g.C, tm, tn, j)), 0, 0x7ffffff0, 0x00020000);
       constexpr unsigned so = 0;
       if constexpr (EM == 2) {
@@ -454,8 +483,9 @@ void gemm_wide_kernel(GemmArgs g) {
   // been issued -> wait for them and for the DMA of the next k-tile, barrier, request the next k-tile's first
   // fragments, run `pre_dma` (block-column epilogues whose stores should be OLDER than the next DMA requests), and
   // refill the stage just released with the k-tile three ahead.
-  auto ktile = [&](auto j0c, auto j1c, unsigned nb0, unsigned nb1, int first_of_block, int blk, auto&& pre_dma, auto fence_c) __attribute__((always_inline)) {
-    constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+  // `tkc` (mode 4): the k-tile's index inside the 256-deep k block, -1 = no mean work (k-tiles mode 4 never reaches)
+  auto ktile = [&](auto j0c, auto j1c, unsigned nb0, unsigned nb1, int first_of_block, int blk, auto&& pre_dma, auto fence_c, auto tkc) __attribute__((always_inline)) {
+    constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value, TK = decltype(tkc)::value;
     constexpr bool FENCE = decltype(fence_c)::value;   // the last pair carries a block-column epilogue: keep its stores ahead of the DMA requests
     constexpr int NACT = J1 - J0 + 1, U = 4 * NACT;
     if constexpr (SCALED) {
@@ -525,6 +555,20 @@ void gemm_wide_kernel(GemmArgs g) {
         constexpr int x = decltype(xc)::value;
         mma1(integral_constant<int, u1>{}, integral_constant<int, x / 4>{}, integral_constant<int, x % 4>{});
       });
+      // mode 4: the unit that starts k-substep `sub` carries the substep's two mean MFMAs and the read of alpha's row for
+      // the next substep (this k-tile's, or the next one's: the tile after a tile starts at k-tile 0 again)
+      constexpr int nmean = (EM == 4 && TK >= 0) ? ((u0 % NACT == 0) ? 1 : 0) + ((u1 % NACT == 0) ? 1 : 0) : 0;
+      auto mean_work = [&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        if constexpr (EM == 4 && TK >= 0 && u % NACT == 0) {
+          constexpr int sub = u / NACT, s8 = sub >> 1, q = sub & 1;
+          macc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[s8][q][0], fm, macc[0], 0, 0, 0);
+          macc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[s8][q][1], fm, macc[1], 0, 0, 0);
+          read_fm(integral_constant<int, (sub < 3 ? TK : ((TK + 1) & 15))>{}, integral_constant<int, ((sub + 1) & 3)>{});
+        }
+      };
+      mean_work(integral_constant<int, u0>{});
+      mean_work(integral_constant<int, u1>{});
       if constexpr (!lastp) {
         // first MFMA (it carries the wait), then one LDS read per MFMA, then the rest
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -533,6 +577,10 @@ void gemm_wide_kernel(GemmArgs g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         });
         __builtin_amdgcn_sched_group_barrier(0x008, 15 - n_ds, 0);
+        if constexpr (nmean > 0) {
+          __builtin_amdgcn_sched_group_barrier(0x100, nmean, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * nmean, 0);
+        }
       } else if constexpr (!FENCE) {
         // the k-tile's last pair: first MFMA, then the next k-tile's first fragment reads and the DMA requests of the
         // k-tile three ahead, ONE per MFMA, so that their ~80 scalar / address instructions issue under the remaining
@@ -548,6 +596,10 @@ void gemm_wide_kernel(GemmArgs g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         });
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        if constexpr (nmean > 0) {
+          __builtin_amdgcn_sched_group_barrier(0x100, nmean, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * nmean, 0);
+        }
       }
     });
     advance(load);
@@ -582,7 +634,7 @@ void gemm_wide_kernel(GemmArgs g) {
       const bool lastblk = blk == nkb - 1;
       if constexpr (DIR == 1) {
         const int nd = 16 * nq;
-        for (int t = 0; t < nd; ++t) { ktile(I0, I7, dn0, dn1, fob, blk, nothing, std::false_type{}); fob = 0; }
+        for (int t = 0; t < nd; ++t) { ktile(I0, I7, dn0, dn1, fob, blk, nothing, std::false_type{}, integral_constant<int, -1>{}); fob = 0; }
       }
       if constexpr (DIR != 0) {
         w_static_for<0, 16>([&](auto tc) __attribute__((always_inline)) {
@@ -621,8 +673,8 @@ void gemm_wide_kernel(GemmArgs g) {
           // (measured: the interleaved last pair gains 1-2 % on Ct / dCt and loses 5 % on the T product, whose deferred
           //  block-column stores share the vmcnt queue with the DMA requests: that kernel keeps the fenced form throughout)
           constexpr bool has_epi = EM != 0 && (jw >= 0 || DIR == 2);
-          if constexpr (DIR == 1) ktile(integral_constant<int, v>{}, I7, nb0, nb1, fob, blk, pre, integral_constant<bool, has_epi>{});
-          else ktile(I0, integral_constant<int, v>{}, nb0, nb1, fob, blk, pre, integral_constant<bool, has_epi>{});
+          if constexpr (DIR == 1) ktile(integral_constant<int, v>{}, I7, nb0, nb1, fob, blk, pre, integral_constant<bool, has_epi>{}, integral_constant<int, (EM == 4 ? t : -1)>{});
+          else ktile(I0, integral_constant<int, v>{}, nb0, nb1, fob, blk, pre, integral_constant<bool, has_epi>{}, integral_constant<int, -1>{});
           fob = 0;
         });
         if constexpr (DIR == 2) pend = false;
@@ -631,7 +683,7 @@ void gemm_wide_kernel(GemmArgs g) {
         const int t0 = DIR == 2 ? 16 * nq + 16 : 0;
         for (int t = t0; t < ktb; ++t) {
           const bool more = t + 1 < ktb;
-          ktile(I0, I7, more ? dn0 : dg0, more ? dn1 : (DIR == 2 ? dg1 : dn1), fob, blk, nothing, std::false_type{});
+          ktile(I0, I7, more ? dn0 : dg0, more ? dn1 : (DIR == 2 ? dg1 : dn1), fob, blk, nothing, std::false_type{}, integral_constant<int, -1>{});
           fob = 0;
         }
       }
@@ -640,6 +692,24 @@ void gemm_wide_kernel(GemmArgs g) {
     if constexpr (EM != 0 && DIR == 1) {
       epi_fetch(I7, cons.tm, cons.tn);
       epi_fast(I7, cons.tm, cons.tn, true, true);
+      if constexpr (EM == 4) {
+        // the tile's mean0 rows: every lane issues its two 8-byte stores (lanes of outputs d >= D aim past the buffer's
+        // records and are dropped), so that the store count the vmcnt scheme relies on does not depend on D
+        int li2 = lane & 15, lk2 = lane >> 4;
+        asm volatile("" : "+v"(li2), "+v"(lk2));
+        const int d = 4 * wc + (li2 & 3);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+            g.mean_out + (long)cons.tm * WBM * g.mean_d, 0, WBM * g.mean_d * 8, 0x00020000);
+        typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = (wr * 2 + i) * 16 + 4 * (li2 >> 2) + lk2;
+          const unsigned vo_m = d < g.mean_d ? (unsigned)((row * g.mean_d + d) * 8) : 0x7ffffff0u;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, macc[i]), rm, vo_m, 0, 0);
+          macc[i] = 0.0;
+        }
+        st_a += 4; st_b += 4;       // (these two and the two row-sum stores of the last block column)
+      }
     } else if constexpr (EM != 0 && DIR == 2) {
       if (has_next) {
         epi_fetch(I0, cons.tm, cons.tn);
@@ -668,6 +738,7 @@ void gemm_wide_kernel(GemmArgs g) {
 
 // Host side (gemm_wide.hip): true when `a` (an NN product) can run on the wide kernel
 bool gemm_wide_ok(const GemmArgs& a);
+bool gemm_wide_mean_ok(const GemmArgs& a);      // `a` runs as mode 4: the launch also writes mean_out = A mean_alpha
 hipError_t gemm_wide(hipStream_t st, const GemmArgs& a);
 
 }  // namespace dgp

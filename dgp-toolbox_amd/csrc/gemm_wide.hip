@@ -57,6 +57,16 @@ bool gemm_wide_ok(const GemmArgs& a) {
   return true;
 }
 
+// mode 4 (gemm_wide.h): the plain forward product with the row sums (epi 2), one 256-column tile per row panel, K = 256
+bool gemm_wide_mean_ok(const GemmArgs& a) {
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("DGP_WIDE_MEAN"); enabled = e ? atoi(e) : 1; }
+  return enabled && a.mean_alpha != nullptr && a.mean_out != nullptr && a.mean_d >= 1 && a.mean_d <= 8 && gemm_wide_ok(a) &&
+         a.tri == TRI_B_UPPER && a.N == WBN && a.K == WBN && a.triblk == WBN && a.alpha == 1.0 && a.rank == 0 && a.eadd == nullptr &&
+         a.epi == 2 && a.C2 == nullptr && a.ascale_mode == 0 && !a.c_blocked && !a.a_blocked &&
+         (reinterpret_cast<uintptr_t>(a.mean_alpha) & 7u) == 0 && (reinterpret_cast<uintptr_t>(a.mean_out) & 7u) == 0;
+}
+
 hipError_t gemm_wide(hipStream_t st, const GemmArgs& a) {
   static int grid_env = -1;
   if (grid_env < 0) { const char* e = getenv("DGP_WIDE_GRID"); grid_env = (e && atoi(e) > 0) ? atoi(e) : 0; }
@@ -73,14 +83,15 @@ hipError_t gemm_wide(hipStream_t st, const GemmArgs& a) {
   // epilogue mode (gemm_wide.h): the interleaved block-column forms for the plain products with one k block per tile
   int em = 0;
   const bool plain = dir != 0 && !sc && a.alpha == 1.0 && a.rank == 0 && a.eadd == nullptr && a.K == a.triblk;
-  if (plain && a.epi == 2 && a.C2 == nullptr) em = 1;
+  if (plain && a.epi == 2 && a.C2 == nullptr) em = (dir == 1 && gemm_wide_mean_ok(a)) ? 4 : 1;
   else if (plain && a.epi == 0 && a.C2 != nullptr && dir == 2) em = 2;
   else if (plain && a.epi == 1) em = 3;
 #define W_LAUNCH(D, S, E) hipLaunchKernelGGL((gemm_wide_kernel<D, S, E>), dim3(grid), dim3(512), 0, st, a)
   if (sc) W_LAUNCH(1, true, 0);
   else if (dir == 0) W_LAUNCH(0, false, 0);
   else if (dir == 1) {
-    if (em == 1) W_LAUNCH(1, false, 1);
+    if (em == 4) W_LAUNCH(1, false, 4);
+    else if (em == 1) W_LAUNCH(1, false, 1);
     else W_LAUNCH(1, false, 0);
   } else {
     if (em == 1) W_LAUNCH(2, false, 1);

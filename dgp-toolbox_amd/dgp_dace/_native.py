@@ -495,11 +495,12 @@ class Context:
         out = {"Ct": np.empty((P, Mp)), "cn": np.empty(P), "T": np.empty((P, D * Mp)), "tn": np.empty((P, D)),
                "mean0": np.empty((P, D)), "Cbar": np.empty((P, Mp)), "g": np.empty((P, Mp)), "du": np.empty((Mp, D)),
                "Gd": np.empty((D, Mp, Mp))}
-        eng = (C.c_int32 * 6)()
+        eng = (C.c_int32 * 7)()
         self._chk(self._lib.dgp_dev_layer_products(self._h, P, Mp, D, _ptr(Kt), _ptr(Linv), _ptr(Wcat), _ptr(u), _ptr(vbar),
                                                    _ptr(mbar), *[_ptr(out[k]) for k in ("Ct", "cn", "T", "tn", "mean0", "Cbar", "g", "du", "Gd")],
                                                    eng))
-        out["engines"] = [self.ENGINES[int(e)] for e in eng]
+        out["engines"] = [self.ENGINES[int(e)] for e in eng[:6]]
+        out["mean_in_ct"] = bool(eng[6])
         return out
 
     def dev_chol(self, A):

@@ -238,7 +238,8 @@ int dgp_dev_gram(dgp_ctx* ctx, const double* C /* [P,256] */, const double* s /*
  *   Cbar = sum_d 2 vbar_pd (T_d W_d^T - Ct) + mbar u^T
  *   g    = (Cbar Linv) .* Kt                          du = Ct^T mbar
  *   Gd[d] = sum_p vbar_pd c_p c_p^T  (lower triangle of [D, Mp, Mp]; with Mp = 256 and enough points du rides on this launch)
- * engines[6] (may be NULL): the kernel family (gemm_engine_of) that ran Ct, T, Cbar, g, du, Gd.                      */
+ * engines[7] (may be NULL): the kernel family (gemm_engine_of) that ran Ct, T, Cbar, g, du, Gd; [6] = 1 when mean0 was
+ * produced inside the Ct launch (as Kt (LinvT u): wide-tile kernel, Mp = 256, D <= 8), 0 when by its own product Ct u.   */
 int dgp_dev_layer_products(dgp_ctx* ctx, int64_t P, int32_t Mp, int32_t D, const double* Kt, const double* Linv,
                            const double* Wcat, const double* u, const double* vbar, const double* mbar, double* Ct,
                            double* cn, double* T, double* tn, double* mean0, double* Cbar, double* g, double* du,

@@ -51,6 +51,8 @@ def check(ctx, P, Mp, D, expect=None, seed=None):
     if expect is not None:
         ran = got["engines"][:3] + (got["engines"][4:6] if len(expect) == 5 else [])
         assert ran == list(expect), (P, Mp, D, got["engines"])
+        # mean0 comes out of the Ct launch (as Kt (LinvT u)) exactly where that one is the wide-tile kernel at Mp = 256, D <= 8
+        assert got["mean_in_ct"] == (expect[0] == "wide" and Mp == 256 and D <= 8 and os.environ.get("DGP_WIDE_MEAN", "1") != "0"), got["mean_in_ct"]
     ref = reference(*ops)
     for k, r in ref.items():
         scale = np.abs(r).max()
