@@ -1221,10 +1221,9 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, cons
   if (with_alpha) RET(G(ctx, 2, GEMM_NN, Mp, D, Mp, dLinvT, Mp, du_, D, dal, D, 1.0, 0));      // alpha = LinvT u, as prep() does
   GemmArgs aC = args_Ct(Pm, Mp, dKt, dLinvT, dCt, cnp, with_alpha ? dal : nullptr, dm0, D);
   GemmArgs aT = args_T(Pm, Mp, D, dCt, dW, dT, tnp, ctx->blocked_t);
-  const bool wide = gemm_wide_ok(aC) && gemm_wide_ok(aT);
-  int nplane = 0;
+  int nplane = 0, nplane_t = 0;
   bool mean_done = false;
-  RET(launch_Ct_T(ctx, aC, aT, dLinv, P, &nplane, &mean_done));
+  RET(launch_Ct_T(ctx, aC, aT, dLinv, P, &nplane, &nplane_t, &mean_done));
   if (!mean_done) RET(GX(ctx, 0, GEMM_NN, args_mean0(Pm, Mp, D, dCt, du_, dm0)));
   // backward (backward_chunk, stored-T form)
   GemmArgs aB = args_Cbar(Pm, Mp, D, dT, dS, dCb, dvb, dCt, dmb, du_, ctx->blocked_t);
@@ -1240,8 +1239,9 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, cons
   RET(GX(ctx, 0, GEMM_TN, aGd));
   if (engines) {
     GemmArgs c2 = aC, t2 = aT;
-    if (!wide) { c2.B = dLinv; c2.no_wide = 1; t2.no_wide = 1; }
-    engines[0] = gemm_engine_of(wide ? GEMM_NN : GEMM_NT, c2);
+    int pc, pt;
+    plan_Ct_T(ctx, c2, t2, dLinv, &pc, &pt);
+    engines[0] = gemm_engine_of(c2.no_wide ? GEMM_NT : GEMM_NN, c2);
     engines[1] = gemm_engine_of(GEMM_NN, t2);
     engines[2] = gemm_engine_of(GEMM_NN, aB);
     engines[3] = gemm_engine_of(GEMM_NN, aG);
@@ -1265,11 +1265,11 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, cons
     for (int q = 0; q < nplane; ++q) s += hpl[(size_t)q * Pm + p];
     cn[p] = s;
   }
-  HIPCHK(hipMemcpy(hpl.data(), tnp, (size_t)Pm * nplane * D * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hpl.data(), tnp, (size_t)Pm * nplane_t * D * 8, hipMemcpyDeviceToHost));
   for (long p = 0; p < P; ++p)
     for (int d = 0; d < D; ++d) {
       double s = 0.0;
-      for (int q = 0; q < nplane; ++q) s += hpl[((size_t)d * nplane + q) * Pm + p];
+      for (int q = 0; q < nplane_t; ++q) s += hpl[((size_t)d * nplane_t + q) * Pm + p];
       tn[p * D + d] = s;
     }
   if (aT.c_blocked) {      // gemm_f64.h: panels of 128 rows, inside a panel blocks of 16 columns, each block 128 x 16 row-major

@@ -786,22 +786,26 @@ GemmArgs args_du(dgp_ctx* ctx, long Pl, int Mp, int D, const double* Ct, const d
   return a;
 }
 
-// Ct then T: on the wide-tile / tall-tile kernels when BOTH apply (they share the layout of the row-norm planes: Mp/128
-// planes), else both on the 128 x 64 engine (Mp/32 planes, the triangular solve as an NT product with the lower Linv)
+// Ct then T.  Each goes to the wide-tile / tall-tile kernels when IT is eligible (row-norm partials in Mp/128 planes), else to
+// the 128 x 64 engine (Mp/32 planes; the triangular solve then as an NT product with the lower Linv): finalize_layer takes
+// the two plane counts separately.  (Until round 3 both had to be eligible: a 12 496-point first layer - one rank's share of
+// 8 - has 784 tiles of T but 98 of Ct, and its T ran on the engine: 212 us instead of ~120.)
 // *mean_done: the Ct launch also wrote mean0 (aC carried alpha and ran as the wide-tile kernel's mode 4)
-int launch_Ct_T(dgp_ctx* ctx, GemmArgs aC, GemmArgs aT, const double* Linv, long Pl, int* nplane, bool* mean_done) {
+void plan_Ct_T(dgp_ctx* ctx, GemmArgs& aC, GemmArgs& aT, const double* Linv, int* nplane_c, int* nplane_t) {
+  const long Mp = aC.N;
+  aC.cu_count = ctx->cu_count; aT.cu_count = ctx->cu_count;
+  const bool wide_c = gemm_wide_ok(aC), wide_t = gemm_wide_ok(aT);
+  if (!wide_c) { aC.B = Linv; aC.no_wide = 1; }
+  if (!wide_t) aT.no_wide = 1;
+  *nplane_c = wide_c ? (int)(Mp / 128) : (int)(Mp / 32);
+  *nplane_t = wide_t ? (int)(Mp / 128) : (int)(Mp / 32);
+}
+int launch_Ct_T(dgp_ctx* ctx, GemmArgs aC, GemmArgs aT, const double* Linv, long Pl, int* nplane_c, int* nplane_t, bool* mean_done) {
   const long Mp = aC.N, D = aT.N / Mp;
   const double tri1 = (double)Pl * Mp * (Mp + 1.0);
-  aC.cu_count = ctx->cu_count; aT.cu_count = ctx->cu_count;
-  const bool wide = gemm_wide_ok(aC) && gemm_wide_ok(aT);
-  *nplane = wide ? (int)(Mp / 128) : (int)(Mp / 32);
-  *mean_done = wide && gemm_wide_mean_ok(aC);
-  if (wide) {
-    RET(GX(ctx, 0, GEMM_NN, aC, tri1 + (*mean_done ? 2.0 * Pl * Mp * D : 0.0), (double)Pl * Mp * 16));
-  } else {
-    aC.B = Linv; aC.no_wide = 1; aT.no_wide = 1;
-    RET(GX(ctx, 0, GEMM_NT, aC, tri1, (double)Pl * Mp * 16));
-  }
+  plan_Ct_T(ctx, aC, aT, Linv, nplane_c, nplane_t);
+  *mean_done = !aC.no_wide && gemm_wide_mean_ok(aC);
+  RET(GX(ctx, 0, aC.no_wide ? GEMM_NT : GEMM_NN, aC, tri1 + (*mean_done ? 2.0 * Pl * Mp * D : 0.0), (double)Pl * Mp * 16));
   RET(GX(ctx, 0, GEMM_NN, aT, tri1 * D, (double)Pl * Mp * 8 * (aT.C ? 1 + D : 1)));
   return DGP_OK;
 }
@@ -826,13 +830,13 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
     // when it applies, else on the 128 x 64 engine (Mp/32 planes, the triangular solve as an NT product).
     GemmArgs aC = args_Ct(Pm, Mp, y.Kt, y.LinvT, y.Ct, y.cnp, y.alpha, y.mean0, D);
     GemmArgs aT = args_T(Pm, Mp, D, y.Ct, y.Wcat, y.Tt, y.tnp, ctx->blocked_t);
-    int nplane = 0;
+    int nplane = 0, nplane_t = 0;
     if (small_fused(ctx, y)) {
       // at most 64 inducing points: Kuf, c, t_d, mean0 and the row norms in ONE launch (small_layer.hip)
       ProfScope ps(ctx, 0, (double)Pl * Mp * (Mp + 1.0) * (1 + D), (double)Pl * Mp * 8 * (2 + D));
       HIPCHK(small_layer_fwd(ctx->st, y.d.kernel_kind, Xin, Pl, row0, Din, P(ctx, y.off_Z), P(ctx, y.off_var), P(ctx, y.off_ls), M, D,
                              y.LinvT, y.Wcat, y.u, y.Kt, y.Et, y.Ct, y.Tt, y.cnp, y.tnp, Pm, y.mean0));
-      nplane = 1;
+      nplane = nplane_t = 1;
     } else {
       {
         ProfScope ps(ctx, 1, 0, (double)Pl * (Mp + Din) * 8);
@@ -843,12 +847,12 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
                          y.Kt, y.Et));
       }
       bool mean_done = false;
-      RET(launch_Ct_T(ctx, aC, aT, y.Linv, Pl, &nplane, &mean_done));
+      RET(launch_Ct_T(ctx, aC, aT, y.Linv, Pl, &nplane, &nplane_t, &mean_done));
       if (!mean_done) RET(GX(ctx, 0, GEMM_NN, args_mean0(Pm, Mp, D, y.Ct, y.u, y.mean0), 2.0 * Pl * Mp * D, (double)Pl * Mp * 8));
     }
     {
-      ProfScope ps(ctx, 1, 0, (double)Pl * nplane * 8 * (1 + D));
-      HIPCHK(finalize_layer(ctx->st, y.cnp, y.tnp, nplane, Pm, y.mean0, Xin, row0, Pl, Nc, S, dedup ? 1 : 0, Din, D,
+      ProfScope ps(ctx, 1, 0, (double)Pl * 8 * (nplane + nplane_t * D));
+      HIPCHK(finalize_layer(ctx->st, y.cnp, y.tnp, nplane, nplane_t, Pm, y.mean0, Xin, row0, Pl, Nc, S, dedup ? 1 : 0, Din, D,
                             P(ctx, y.off_var), y.d.mean_kind, y.meanW, y.meanb,
                             zsrc_of(ctx, l, use_zs, seed, n_goff, Ntot), n0, y.mean, y.var, y.F, y.d.kernel_kind,
                             y.off_white >= 0 ? P(ctx, y.off_white) : nullptr));

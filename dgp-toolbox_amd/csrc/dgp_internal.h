@@ -133,7 +133,7 @@ hipError_t rbf_kuf(hipStream_t st, int kind, const double* Xin, long P, long x_r
 // var/mean/sample stage of a layer (layers.py:249-278 + utils.py:41) from the GEMM epilogue partials.
 // `dedup`: the P rows are the Nc data points of the first layer (identical for every sample s); F is always
 // written for all S*Nc rows.
-hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, int nplane,
+hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, int nplane /* of cnp */, int nplane_t /* per d, of tnp */,
                           long pstride /* rows per partial plane */, const double* mean0,
                           const double* Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
                           const double* kvar, int mean_kind, const double* meanW, const double* meanb, ZSource zsrc,

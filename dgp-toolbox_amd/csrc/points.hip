@@ -214,7 +214,7 @@ hipError_t rbf_kuf(hipStream_t st, int kind, const double* Xin, long P, long x_r
 //   F = mean + z sqrt(var + jitter)      (utils.py:41)
 // One thread per (d, p), p fastest (coalesced plane reads).
 __global__ __launch_bounds__(256) void finalize_layer_kernel(
-    const double* __restrict__ cnp, const double* __restrict__ tnp, int nplane, long pstride,
+    const double* __restrict__ cnp, const double* __restrict__ tnp, int nplane, int nplane_t, long pstride,
     const double* __restrict__ mean0,
     const double* __restrict__ Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
     const double* __restrict__ kvar, int mean_kind, const double* __restrict__ meanW, const double* __restrict__ meanb,
@@ -225,10 +225,8 @@ __global__ __launch_bounds__(256) void finalize_layer_kernel(
   const int d = (int)(idx / P);
   const long p = idx % P;
   double cn = 0.0, tn = 0.0;
-  for (int q = 0; q < nplane; ++q) {
-    cn += cnp[(long)q * pstride + p];
-    tn += tnp[((long)d * nplane + q) * pstride + p];
-  }
+  for (int q = 0; q < nplane; ++q) cn += cnp[(long)q * pstride + p];
+  for (int q = 0; q < nplane_t; ++q) tn += tnp[((long)d * nplane_t + q) * pstride + p];
   const double* x = Xin + (x_row0 + p) * Din;
   double mf = 0.0;
   if (mean_kind == 1) mf = x[d];
@@ -263,7 +261,7 @@ __global__ __launch_bounds__(256) void finalize_layer_kernel(
 // (the per-point kernel above wrote them 8 bytes per lane at a stride of D doubles: 0.45 ms at P = 1e6, D = 8; the planes
 // are summed in the same order, so the results are bit-identical).
 __global__ __launch_bounds__(256) void finalize_layer_tiled_kernel(
-    const double* __restrict__ cnp, const double* __restrict__ tnp, int nplane, long pstride,
+    const double* __restrict__ cnp, const double* __restrict__ tnp, int nplane, int nplane_t, long pstride,
     const double* __restrict__ mean0,
     const double* __restrict__ Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
     const double* __restrict__ kvar, int mean_kind, const double* __restrict__ meanW, const double* __restrict__ meanb,
@@ -287,7 +285,7 @@ __global__ __launch_bounds__(256) void finalize_layer_tiled_kernel(
     if (pt < P)
       for (int dd = 0; dd < dn; ++dd) {
         double tn = 0.0;
-        for (int q = 0; q < nplane; ++q) tn += tnp[((long)(d0 + dd) * nplane + q) * pstride + pt];
+        for (int q = 0; q < nplane_t; ++q) tn += tnp[((long)(d0 + dd) * nplane_t + q) * pstride + pt];
         s_tn[dd][t] = tn;
       }
     __syncthreads();
@@ -336,7 +334,7 @@ __global__ __launch_bounds__(256) void expand_f_kernel(const double* __restrict_
   F[idx] = mean[r] + draw_z(zsrc, s, n_chunk0 + p, d, D) * sqrt(var[r] + kJitter);
 }
 
-hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, int nplane, long pstride,
+hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, int nplane, int nplane_t, long pstride,
                           const double* mean0,
                           const double* Xin, long x_row0, long P, long Nc, int S, int dedup, int Din, int D,
                           const double* kvar, int mean_kind, const double* meanW, const double* meanb, ZSource zsrc,
@@ -348,11 +346,11 @@ hipError_t finalize_layer(hipStream_t st, const double* cnp, const double* tnp, 
   const bool wide_s = dedup && F != nullptr && S > 16;
   double* Fk = wide_s ? nullptr : F;
   if (P >= 32768 && D > 1)
-    hipLaunchKernelGGL(finalize_layer_tiled_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, cnp, tnp, nplane, pstride,
+    hipLaunchKernelGGL(finalize_layer_tiled_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, cnp, tnp, nplane, nplane_t, pstride,
                        mean0, Xin, x_row0, P, Nc, S, dedup, Din, D, kvar, mean_kind, meanW, meanb, zsrc, n_chunk0, mean, var, Fk,
                        kernel_kind, white);
   else
-    hipLaunchKernelGGL(finalize_layer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cnp, tnp, nplane, pstride, mean0,
+    hipLaunchKernelGGL(finalize_layer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cnp, tnp, nplane, nplane_t, pstride, mean0,
                        Xin, x_row0, P, Nc, S, dedup, Din, D, kvar, mean_kind, meanW, meanb, zsrc, n_chunk0, mean, var, Fk,
                        kernel_kind, white);
   if (wide_s) {

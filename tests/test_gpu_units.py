@@ -105,7 +105,9 @@ PRODUCTION_CASES = [
     (98304, 256, 1, ("wide", "tall", "tallu", "gram", "gram")),
     (98304 + 384, 256, 3, ("wide", "tall", "tallu", "gram", "gram")),
     (49152 + 128, 512, 2, ("wide", "wide", "wide")),          # BASELINE config 4's inducing count
-    (20000, 256, 8, ("engine128x64", "engine128x64", "engine128x64")),   # below the limits: the 128 x 64 engine, padded rows
+    (20000, 256, 8, ("engine128x64", "tall", "engine128x64")),   # below the limits of Ct / dC (157 tiles): the 128 x 64 engine, padded rows; T (1256 tiles) is eligible on its own
+    (12496, 256, 8, ("engine128x64", "tall", "engine128x64")),   # one rank's share of 8: the first layer's shape
+    (12496, 256, 1, ("engine128x64", "engine128x64", "engine128x64")),
     (3001, 192, 2, ("engine128x64", "engine128x64", "engine128x64")),
 ]
 
