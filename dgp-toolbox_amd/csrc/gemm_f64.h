@@ -755,6 +755,9 @@ hipError_t gemm_tall(hipStream_t st, const GemmArgs& a);
 bool gemm_tallu_ok(const GemmArgs& a);
 hipError_t gemm_tallu(hipStream_t st, const GemmArgs& a);
 // weighted Gram products over the points (gemm_gram.h / gemm_gram.hip)
+// latency-oriented products of the chains' Mp x Mp matrices (gemm_mid.hip)
+bool gemm_mid_ok(GemmOp op, const GemmArgs& a);
+hipError_t gemm_mid(hipStream_t st, GemmOp op, const GemmArgs& a);
 bool gemm_gram_ok(const GemmArgs& a);
 long gemm_gram_ws_bytes(int cu_count);      // cu_count <= 0: the current device
 hipError_t gemm_gram(hipStream_t st, const GemmArgs& a);

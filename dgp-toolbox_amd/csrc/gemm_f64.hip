@@ -183,6 +183,7 @@ int gemm_engine_of(GemmOp op, const GemmArgs& args) {
   if (a.splits < 1) a.splits = 1;
   if (a.batch < 1) a.batch = 1;
   if (gemm_small_ok(op, a)) return 5;      // M, N, K <= 64: one workgroup, operands staged once
+  if (gemm_mid_ok(op, a)) return 6;        // the chains' Mp x Mp products (K <= 256, few engine tiles): 32 x 32 tiles, k range staged once
   // row-panel products with a (block-)triangular or dense Mp-wide B: the tall-tile kernels, else the wide-tile kernel
   if (op == GEMM_NN && !a.no_wide && gemm_tall_ok(a)) return 2;      // T = Ct * Wcat at Mp = 256: 256 x 128 tiles
   if (op == GEMM_NN && !a.no_wide && gemm_tallu_ok(a)) return 3;     // dC = [2 vbar .* T] * W^T ... at Mp = 256, likewise
@@ -203,6 +204,7 @@ hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args) {
   }
   switch (gemm_engine_of(op, a)) {
     case 5: return gemm_small(st, op, a);
+    case 6: return gemm_mid(st, op, a);
     case 2: return gemm_tall(st, a);
     case 3: return gemm_tallu(st, a);
     case 1: return gemm_wide(st, a);

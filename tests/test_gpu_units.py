@@ -20,10 +20,13 @@ def _rel(a, b):
 @pytest.mark.parametrize("op", ["NN", "NT", "TN"])
 @pytest.mark.parametrize("shape", [(300, 256, 64), (128, 128, 16), (1000, 48, 48), (37, 130, 50), (256, 8, 640),
                                    (513, 3, 77), (64, 272, 272), (64, 64, 64), (37, 50, 61), (5, 64, 33), (64, 3, 64),
-                                   (1, 1, 1)])
+                                   (1, 1, 1), (256, 256, 256), (128, 128, 128), (256, 8, 256), (512, 512, 256), (100, 70, 130),
+                                   (97, 33, 255), (1024, 16, 250)])
 def test_gemm_matches_numpy(ctx, op, shape):
     """MFMA operand/accumulator lane maps, LDS images, tails: asymmetric random operands.  The shapes with M, N, K <= 64
-    run in the one-workgroup kernel of gemm_small.hip."""
+    run in the one-workgroup kernel of gemm_small.hip; those with K <= 256, M, N <= 1024 and few 128 x 64 tiles (the chains'
+    Mp x Mp products, the last seven and several of the others) in the 32 x 32-tile kernel of gemm_mid.hip, edges and k tails
+    (K % 4 != 0) included; the rest on the 128 x 64 engine."""
     M, N, K = shape
     rng = np.random.default_rng(M * 7 + N * 3 + K)
     A = rng.standard_normal((K, M) if op == "TN" else (M, K))
