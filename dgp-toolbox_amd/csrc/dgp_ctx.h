@@ -92,6 +92,7 @@ struct dgp_ctx {
   double data_scale = 1.0;          // factor on the data term (N / batch size for a minibatch estimate)
   double *acc = nullptr, *acc_own = nullptr;
   double *gram_ws = nullptr;                         // partial triangles of the weighted Gram kernel (layers with Mp = 256)
+  double *rg_ws = nullptr;                           // per-workgroup GX partials of the one-pass R1 / GX kernel (points.hip: rbf_bwd_contract)
   double *sl_ws = nullptr;                           // per-block partial sums of the fused small-layer backward (small_layer.hip)
   long n_acc = 0;
   double* scal = nullptr;   // device scalars: [0] sum KL, [1] ELBO of last grad_finish, [2] scratch data term
@@ -403,7 +404,7 @@ void free_model(dgp_ctx* ctx) {
   }
   ctx->L.clear();
   dev_free(ctx->params); dev_free(ctx->grad); dev_free(ctx->adam_m); dev_free(ctx->adam_v);
-  dev_free(ctx->segs_dev); dev_free(ctx->mean_params); dev_free(ctx->acc_own); dev_free(ctx->gram_ws); dev_free(ctx->sl_ws);
+  dev_free(ctx->segs_dev); dev_free(ctx->mean_params); dev_free(ctx->acc_own); dev_free(ctx->gram_ws); dev_free(ctx->sl_ws); dev_free(ctx->rg_ws);
   ctx->acc = nullptr;
   for (auto& set : ctx->smset) for (auto& s : set) dev_free(s);
   for (auto& z : ctx->zs_dev) dev_free(z);
@@ -980,11 +981,17 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
         ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 16);
         HIPCHK(make_x1(ctx->st, Xin, row0, Pl, Din, ctx->X1));
       }
-      RET(GX(ctx, 0, GEMM_NN, mk(Pm, w1, Mp, ctx->Gt, Mp, y.Z1, w1, ctx->R1, w1), 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
-      if (o.params) {
-        GemmArgs a = mk(Mp, w1, Pl, ctx->Gt, Mp, ctx->X1, w1, acc + y.acc_GX, w1, 1.0, 1);
-        a.splits = pick_splits(ctx, Mp, w1, Pl);
-        RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
+      if (rbf_bwd_contract_ok(Mp, w1, Pl)) {      // both contractions in one pass over g (points.hip)
+        if (o.params && !ctx->rg_ws) RET(dev_alloc(ctx, &ctx->rg_ws, (size_t)rbf_bwd_contract_ws_doubles()));
+        ProfScope ps(ctx, 0, (o.params ? 4.0 : 2.0) * Pl * Mp * w1, (double)Pl * Mp * 8);
+        HIPCHK(rbf_bwd_contract(ctx->st, ctx->Gt, Pl, y.Z1, ctx->X1, w1, ctx->R1, o.params ? acc + y.acc_GX : nullptr, ctx->rg_ws));
+      } else {
+        RET(GX(ctx, 0, GEMM_NN, mk(Pm, w1, Mp, ctx->Gt, Mp, y.Z1, w1, ctx->R1, w1), 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
+        if (o.params) {
+          GemmArgs a = mk(Mp, w1, Pl, ctx->Gt, Mp, ctx->X1, w1, acc + y.acc_GX, w1, 1.0, 1);
+          a.splits = pick_splits(ctx, Mp, w1, Pl);
+          RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
+        }
       }
       ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 24);
       HIPCHK(xbar_finish(ctx->st, ctx->R1, ctx->X1, Pl, P(ctx, y.off_ls), Din, D, y.d.mean_kind, y.meanW, y.mbar,

@@ -181,6 +181,11 @@ hipError_t small_prep(hipStream_t st, const double* q_sqrt, const double* q_mu, 
                       double* Lu, double* Linv, double* LinvT, double* Wcat, double* u, double* Scat /* null: not wanted */,
                       double* Z1 /* null: not wanted */, double* kl_out, int* info);
 hipError_t make_x1(hipStream_t st, const double* Xin, long x_row0, long P, int Din, double* X1);     // [X | 1]
+// R1 = g [Z | 1] and (GX != nullptr) GX += g^T [X | 1] in one pass over g: Mp = 256, w1 = D_in + 1 <= 9 (points.hip)
+bool rbf_bwd_contract_ok(int Mp, int w1, long P);
+long rbf_bwd_contract_ws_doubles();
+hipError_t rbf_bwd_contract(hipStream_t st, const double* G, long P, const double* Z1, const double* X1, int w1, double* R1,
+                            double* GX, double* ws);
 hipError_t xbar_finish(hipStream_t st, const double* R1, const double* X1, long P, const double* ls, int Din, int D,
                        int mean_kind, const double* meanW, const double* mbar, int want_xbar, double* xbar,
                        double* acc_x2rs);

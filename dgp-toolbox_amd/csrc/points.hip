@@ -615,6 +615,151 @@ hipError_t make_x1(hipStream_t st, const double* Xin, long x_row0, long P, int D
   LAUNCH_CHECK();
 }
 
+// R1 = g [Z | 1] and GX += g^T [X | 1] in ONE pass over g (Mp = 256, D_in <= 8).  As two skinny products on the 128 x 64 engine
+// each of them streamed g (2 GB per 10^6 points) at HBM speed: 0.41 + 0.36 ms.  Here a workgroup walks a contiguous range of
+// 16-point tiles: thread t loads column t of the tile's 16 rows (coalesced 2 KB rows, the next tile's 16 loads in flight while
+// this one is worked on) and parks them in LDS; then, on the matrix cores (v_mfma_f64_4x4x4_4b_f64, lane maps: gemm_f64.h),
+//   R1 tile [16 x 12] = g tile [16 x 256] Z1p [256 x 12]: the 64 k-steps split over the four waves, partials met in LDS;
+//   GX [256 x 12]    += g tile^T [256 x 16] X1p tile [16 x 12]: wave w owns columns 64 w .. 64 w + 63, accumulators kept over
+//                       the workgroup's whole range, written once to a slab that rg_reduce_kernel adds in a fixed order.
+// "p": the W <= 9 real columns sit at 4 (j / 3) + j % 3 of 12 (the e-th of three MFMAs yields columns 4 q + e).
+// (A first version did both on the VALU, one LDS operand read per FMA: LDS-bound, 1.07 ms per 10^6 points.)
+constexpr int RG_TP = 16, RG_PITCH = 260;
+template <int W>
+__global__ __launch_bounds__(256) void rg_contract_kernel(const double* __restrict__ G, long P, const double* __restrict__ Z1,
+                                                          const double* __restrict__ X1, double* __restrict__ R1,
+                                                          double* __restrict__ slab, long tiles_per_wg) {
+  __shared__ __attribute__((aligned(16))) double sG[RG_TP * RG_PITCH];
+  __shared__ __attribute__((aligned(16))) double sZ[256 * 12];
+  __shared__ __attribute__((aligned(16))) double sX[RG_TP * 12];
+  __shared__ double sP[4 * 64 * 3];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lk = lane >> 4;
+  for (int x = t; x < 256 * 12; x += 256) {
+    const int m = x / 12, jj = x - m * 12, j = 3 * (jj >> 2) + (jj & 3);
+    sZ[x] = ((jj & 3) < 3 && j < W) ? Z1[m * W + j] : 0.0;
+  }
+  if (t < RG_TP * 12) sX[t] = 0.0;
+  double gacc[4][3];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) gacc[b][e] = 0.0;
+  const long ntile = (P + RG_TP - 1) / RG_TP;
+  const long t0 = (long)blockIdx.x * tiles_per_wg;
+  const long t1 = t0 + tiles_per_wg < ntile ? t0 + tiles_per_wg : ntile;
+  // thread -> element of the X1 tile it stages (t < 16 W) and of the R1 tile it writes
+  const int xp = t / W, xj = t - xp * W, xjj = 4 * (xj / 3) + xj % 3;
+  double gv[RG_TP], xv = 0.0;
+  auto load_tile = [&](long tile) __attribute__((always_inline)) {
+    const long p0 = tile * RG_TP;
+    const int np = (int)(P - p0 < RG_TP ? P - p0 : RG_TP);
+#pragma unroll
+    for (int pp = 0; pp < RG_TP; ++pp) gv[pp] = pp < np ? G[(p0 + pp) * 256 + t] : 0.0;
+    xv = (t < RG_TP * W && xp < np) ? X1[(p0 + xp) * W + xj] : 0.0;
+  };
+  if (t0 < t1) load_tile(t0);
+  for (long tile = t0; tile < t1; ++tile) {
+    const long p0 = tile * RG_TP;
+    const int np = (int)(P - p0 < RG_TP ? P - p0 : RG_TP);
+    __syncthreads();              // (the previous tile's MFMAs have left sG / sX / sP; first tile: sZ is in place)
+#pragma unroll
+    for (int pp = 0; pp < RG_TP; ++pp) sG[pp * RG_PITCH + t] = gv[pp];
+    if (t < RG_TP * W) sX[xp * 12 + xjj] = xv;
+    __syncthreads();
+    if (tile + 1 < t1) load_tile(tile + 1);
+    // ---- R1 partial of this wave: k-steps 16 wave .. 16 wave + 15 (columns m = 4 s + lk of g)
+    double racc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ss = 0; ss < 16; ++ss) {
+      const int s = 16 * wave + ss;
+      const double a = sG[li * RG_PITCH + 4 * s + lk];
+      const double* zp = sZ + (4 * s + lk) * 12 + 4 * (li & 3);
+      const d2_t z01 = *reinterpret_cast<const d2_t*>(zp);
+      const double z2 = zp[2];
+      racc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, z01[0], racc[0], 0, 0, 0);
+      racc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, z01[1], racc[1], 0, 0, 0);
+      racc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, z2, racc[2], 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) sP[(wave * 64 + lane) * 3 + e] = racc[e];
+    // ---- GX: this wave's four 16-column blocks, k = the tile's 16 points
+    if (slab != nullptr) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double* xq = sX + (4 * s + lk) * 12 + 4 * (li & 3);
+        const d2_t x01 = *reinterpret_cast<const d2_t*>(xq);
+        const double x2 = xq[2];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double a = sG[(4 * s + lk) * RG_PITCH + 16 * (4 * wave + b) + li];
+          gacc[b][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x01[0], gacc[b][0], 0, 0, 0);
+          gacc[b][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x01[1], gacc[b][1], 0, 0, 0);
+          gacc[b][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, x2, gacc[b][2], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    // R1[p0 + xp][xj] = the four waves' partials of lane (c = 4 (xp >> 2) + xj / 3, lk = xp & 3), MFMA e = xj % 3
+    if (t < RG_TP * W && xp < np) {
+      const int ln = 4 * (xp >> 2) + xj / 3 + 16 * (xp & 3), e = xj % 3;
+      R1[(p0 + xp) * W + xj] = (sP[(0 * 64 + ln) * 3 + e] + sP[(1 * 64 + ln) * 3 + e]) + (sP[(2 * 64 + ln) * 3 + e] + sP[(3 * 64 + ln) * 3 + e]);
+    }
+  }
+  if (slab != nullptr) {
+    // gacc[b][e] of lane (c = li, lk) is GX[16 (4 wave + b) + 4 (c >> 2) + lk][3 (c & 3) + e]
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int m = 16 * (4 * wave + b) + 4 * (li >> 2) + lk, j = 3 * (li & 3) + e;
+        if (j < W) slab[((long)blockIdx.x * 256 + m) * W + j] = gacc[b][e];
+      }
+  }
+}
+// GX[m][j] += sum over the workgroups' slabs, in workgroup order; one thread per (m, j)
+__global__ __launch_bounds__(256) void rg_reduce_kernel(const double* __restrict__ slab, int nslab, int n, double* __restrict__ GX) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = 0;
+  for (; b + 4 <= nslab; b += 4) {
+    s0 += slab[(long)(b + 0) * n + i]; s1 += slab[(long)(b + 1) * n + i];
+    s2 += slab[(long)(b + 2) * n + i]; s3 += slab[(long)(b + 3) * n + i];
+  }
+  for (; b < nslab; ++b) s0 += slab[(long)b * n + i];
+  GX[i] += (s0 + s1) + (s2 + s3);
+}
+constexpr int RG_MAX_WG = 512;      // two workgroups per CU (65 KB of LDS each)
+long rbf_bwd_contract_ws_doubles() { return (long)RG_MAX_WG * 256 * 9; }
+bool rbf_bwd_contract_ok(int Mp, int w1, long P) {
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("DGP_RG_FUSED"); enabled = e ? atoi(e) : 1; }
+  return enabled && Mp == 256 && w1 >= 2 && w1 <= 9 && P >= 2048;
+}
+// R1 [P x w1] = G Z1; GX [256 x w1] += G^T X1 when GX != nullptr (ws: rbf_bwd_contract_ws_doubles() doubles)
+hipError_t rbf_bwd_contract(hipStream_t st, const double* G, long P, const double* Z1, const double* X1, int w1, double* R1,
+                            double* GX, double* ws) {
+  if (P <= 0) return hipSuccess;
+  if (GX != nullptr && ws == nullptr) return hipErrorInvalidValue;
+  const long ntile = (P + RG_TP - 1) / RG_TP;
+  const long grid = ntile < RG_MAX_WG ? ntile : RG_MAX_WG;
+  const long per = (ntile + grid - 1) / grid;
+  const long used = (ntile + per - 1) / per;          // workgroups that get tiles (the others would write zero slabs)
+  double* slab = GX ? ws : nullptr;
+#define RG_LAUNCH(W) hipLaunchKernelGGL(rg_contract_kernel<W>, dim3((unsigned)used), dim3(256), 0, st, G, P, Z1, X1, R1, slab, per)
+  switch (w1) {
+    case 2: RG_LAUNCH(2); break; case 3: RG_LAUNCH(3); break; case 4: RG_LAUNCH(4); break; case 5: RG_LAUNCH(5); break;
+    case 6: RG_LAUNCH(6); break; case 7: RG_LAUNCH(7); break; case 8: RG_LAUNCH(8); break; case 9: RG_LAUNCH(9); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef RG_LAUNCH
+  if (GX) {
+    const int n = 256 * w1;
+    hipLaunchKernelGGL(rg_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, (int)used, n, GX);
+  }
+  LAUNCH_CHECK();
+}
+
 // x-gradient of the stationary kernels and the sum over the points of x_j^2 rowsum(g) (the lengthscale gradient's second
 // part).  One thread per (point, input j) in memory order of the [P, Din] arrays: xbar, mbar (identity mean) and the rows of
 // R1 / X1 are touched as contiguous pieces (the first version gave every j its own blocks, each striding over 72-byte rows:
