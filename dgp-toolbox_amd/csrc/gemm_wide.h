@@ -562,8 +562,11 @@ void gemm_wide_kernel(GemmArgs g) {
         constexpr int u = decltype(uc)::value;
         if constexpr (EM == 4 && TK >= 0 && u % NACT == 0) {
           constexpr int sub = u / NACT, s8 = sub >> 1, q = sub & 1;
-          macc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[s8][q][0], fm, macc[0], 0, 0, 0);
-          macc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[s8][q][1], fm, macc[1], 0, 0, 0);
+          // (tied accumulators, as in gemm_gram.h: with the builtin the allocator renamed around these two and spilled 17 registers
+          //  into the k-tile stream - reloads that wait on the DMA queue; tied: 3, all outside it.  The operands come from LDS
+          //  reads, the next use of macc[i] is a k-substep away, the tile's stores wait out the last one: see there.)
+          asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(macc[0]) : "v"(fa[s8][q][0]), "v"(fm));
+          asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(macc[1]) : "v"(fa[s8][q][1]), "v"(fm));
           read_fm(integral_constant<int, (sub < 3 ? TK : ((TK + 1) & 15))>{}, integral_constant<int, ((sub + 1) & 3)>{});
         }
       };
@@ -700,6 +703,7 @@ void gemm_wide_kernel(GemmArgs g) {
         const int d = 4 * wc + (li2 & 3);
         const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
             g.mean_out + (long)cons.tm * WBM * g.mean_d, 0, WBM * g.mean_d * 8, 0x00020000);
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // MFMA results -> stores: the wait states hipcc cannot see (asm MFMAs)
         typedef unsigned u2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
