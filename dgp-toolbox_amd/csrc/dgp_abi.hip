@@ -495,8 +495,7 @@ int dgp_grad_partial(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const
   ctx->grad_ready = false;
   if (zs) RET(upload_zs(ctx, zs, S, ctx->N));
   SideJoin join{ctx, ctx->st, ctx->use_side && ctx->events_ok};
-  RET(prep(ctx, true, true));      // the upper layers' chains run under the first layer's forward pass
-  HIPCHK(hipMemsetAsync(ctx->acc, 0, ctx->n_acc * 8, ctx->st));
+  RET(prep(ctx, true, true, true));      // the upper layers' chains run under the first layer's forward pass; the partial sums start at zero
   long Nc = 0;
   const long lo = ctx->batch_n ? ctx->batch_lo : 0, hi = ctx->batch_n ? ctx->batch_lo + ctx->batch_n : ctx->N;
   RET(ensure_ws(ctx, hi - lo, S, true, &Nc));
@@ -614,8 +613,7 @@ static int finish_layer(dgp_ctx* ctx, size_t li) {
 }
 
 static int finish_tail(dgp_ctx* ctx) {
-  HIPCHK(copy_mat(ctx->st, ctx->acc + 1, ctx->grad + ctx->n_params - 1, 1));
-  HIPCHK(sub_scalars(ctx->st, ctx->acc + 0, ctx->scal + 0, ctx->scal + 1));   // ELBO = data term - sum KL
+  HIPCHK(finish_tail_launch(ctx->st, ctx->acc, ctx->scal, ctx->grad + ctx->n_params - 1));   // ELBO = data term - sum KL
   ctx->grad_ready = true;
   return DGP_OK;
 }
@@ -765,11 +763,16 @@ int after_layer_hook(dgp_ctx* ctx, int l, int phase) {
   }
   hipStream_t chain_st = main_st, comm_st = main_st;
   int w = 0;
+  // the first layer is the last one the backward pass leaves: nothing follows on the main stream that its chain could run
+  // beside, so it stays there (one cross-stream hand-over less at the tail of every iteration)
+  const bool on_main = (l == 0);
   if (side) {
-    w = 1 + ((nl - 1 - l) % 2);                 // alternate the two chain streams, top layer first
-    chain_st = ctx->side[w - 1];
+    if (!on_main) {
+      w = 1 + ((nl - 1 - l) % 2);               // alternate the two chain streams, top layer first
+      chain_st = ctx->side[w - 1];
+      ctx->side_touched[w - 1] = true;
+    }
     comm_st = ctx->side[dgp_ctx::kSide - 1];
-    ctx->side_touched[w - 1] = true;
   }
   if (comm) {
     if (side) { HIPCHK(hipStreamWaitEvent(comm_st, ctx->ev_layer[l], 0)); ctx->side_touched[dgp_ctx::kSide - 1] = true; }
@@ -784,7 +787,7 @@ int after_layer_hook(dgp_ctx* ctx, int l, int phase) {
       HIPCHK(hipEventRecord(ctx->ev_red[l], comm_st));
       HIPCHK(hipStreamWaitEvent(chain_st, ctx->ev_red[l], 0));
     }
-  } else if (side) {
+  } else if (side && !on_main) {
     HIPCHK(hipStreamWaitEvent(chain_st, ctx->ev_layer[l], 0));
   }
   ctx->st = chain_st;
@@ -805,8 +808,7 @@ int dgp_grad_step(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* z
   const int nl = (int)ctx->L.size();
   {
     SideJoin join{ctx, ctx->st, ctx->use_side && ctx->events_ok};
-    RET(prep(ctx, true, true));
-    HIPCHK(hipMemsetAsync(ctx->acc, 0, ctx->n_acc * 8, ctx->st));
+    RET(prep(ctx, true, true, true));      // (the partial sums start at zero)
     long Nc = 0;
     const long lo = ctx->batch_n ? ctx->batch_lo : 0, hi = ctx->batch_n ? ctx->batch_lo + ctx->batch_n : ctx->N;
     RET(ensure_ws(ctx, hi - lo, S, true, &Nc));

@@ -655,15 +655,18 @@ int prep_deferred_layers(dgp_ctx* ctx) {
 
 // `overlap`: the first layer's chain on the context's stream now, the others deferred to prep_deferred_layers (the first
 // layer's forward pass covers them); without it all chains run at once on three workers and are joined here.
-int prep(dgp_ctx* ctx, bool train = false, bool overlap = false) {
+// `zero_acc`: the partial-sum buffer is zeroed by the same launch as the scalars (a training step's two fills in one)
+int prep(dgp_ctx* ctx, bool train = false, bool overlap = false, bool zero_acc = false) {
+  double* za = zero_acc ? ctx->acc : nullptr;
+  const long zn = zero_acc ? ctx->n_acc : 0;
   if (ctx->prep_level >= (train ? 2 : 1)) {        // parameters unchanged: keep the factorisation and the KL in scal[0]
-    HIPCHK(hipMemsetAsync(ctx->scal + 1, 0, 3 * sizeof(double), ctx->st));
+    HIPCHK(zero_two(ctx->st, ctx->scal + 1, 3, za, zn));
     return DGP_OK;
   }
   ctx->prep_level = 0;        // set only once every layer's chain has been enqueued: an error return below must not
                               // leave a half-built factorisation marked as current
   ctx->prep_deferred = false;
-  HIPCHK(hipMemsetAsync(ctx->scal, 0, 4 * sizeof(double), ctx->st));
+  HIPCHK(zero_two(ctx->st, ctx->scal, 4, za, zn));
   const bool ov = overlap && ctx->use_side && ctx->events_ok && ctx->L.size() > 1 && ctx->L.size() <= (size_t)dgp_ctx::kMaxEv;
   if (ov) {
     HIPCHK(hipEventRecord(ctx->ev_fork, ctx->st));      // (the side streams start behind the previous parameter update)

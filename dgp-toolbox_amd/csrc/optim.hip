@@ -53,6 +53,29 @@ hipError_t adam_apply(hipStream_t st, double* params, const double* grad_elbo, d
   return hipGetLastError();
 }
 
+// a[0 .. na) = 0 and b[0 .. nb) = 0 in one launch (the four ELBO / KL scalars and the partial-sum buffer at the head of an
+// iteration: two fill launches of ~5 us each were two of a small model's ~23)
+__global__ void zero_two_kernel(double* __restrict__ a, long na, double* __restrict__ b, long nb) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < na) a[i] = 0.0;
+  if (i < nb) b[i] = 0.0;
+}
+hipError_t zero_two(hipStream_t st, double* a, long na, double* b, long nb) {
+  const long n = na > nb ? na : nb;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(zero_two_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, na, b, nb);
+  return hipGetLastError();
+}
+// the tail of a gradient evaluation: d ELBO / d likelihood variance out of the partial-sum buffer, ELBO = data term - sum KL
+__global__ void finish_tail_kernel(const double* __restrict__ acc, double* __restrict__ scal, double* __restrict__ grad_last) {
+  grad_last[0] = acc[1];
+  scal[1] = acc[0] - scal[0];
+}
+hipError_t finish_tail_launch(hipStream_t st, const double* acc, double* scal, double* grad_last) {
+  hipLaunchKernelGGL(finish_tail_kernel, dim3(1), dim3(1), 0, st, acc, scal, grad_last);
+  return hipGetLastError();
+}
+
 __global__ void iter_bump_kernel(double* it, int seed_inc, int t_inc) {
   uint64_t* seed = reinterpret_cast<uint64_t*>(it);
   seed[0] += (uint64_t)seed_inc;
