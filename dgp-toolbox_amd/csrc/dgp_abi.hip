@@ -1286,6 +1286,31 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, cons
   return DGP_OK;
 }
 
+int dgp_dev_rbf_contract(dgp_ctx* ctx, const double* G, const double* Z1, const double* X1, int64_t Pn, int32_t Mp, int32_t w1,
+                         double* R1, double* GX, int32_t* fused) {
+  if (!ctx || !G || !Z1 || !X1 || !R1 || !GX || Pn <= 0 || Mp <= 0 || Mp % 64 != 0 || w1 < 1 || w1 > 64)
+    return fail(ctx, DGP_ERR_INVALID, "dgp_dev_rbf_contract: bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  const long P = Pn, Pm = pad_rows(P);
+  double *dG = nullptr, *dZ = nullptr, *dX = nullptr, *dR = nullptr, *dGX = nullptr;
+  struct Free { double **a, **b, **c, **d, **e; ~Free() { dev_free(*a); dev_free(*b); dev_free(*c); dev_free(*d); dev_free(*e); } } freer{&dG, &dZ, &dX, &dR, &dGX};
+  RET(dev_alloc(ctx, &dG, (size_t)Pm * Mp)); RET(dev_alloc(ctx, &dZ, (size_t)Mp * w1)); RET(dev_alloc(ctx, &dX, (size_t)Pm * w1));
+  RET(dev_alloc(ctx, &dR, (size_t)Pm * w1)); RET(dev_alloc(ctx, &dGX, (size_t)Mp * w1));
+  HIPCHK(hipMemsetAsync(dG, 0, (size_t)Pm * Mp * 8, ctx->st));
+  HIPCHK(hipMemsetAsync(dX, 0, (size_t)Pm * w1 * 8, ctx->st));
+  HIPCHK(hipMemcpyAsync(dG, G, (size_t)P * Mp * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(dZ, Z1, (size_t)Mp * w1 * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(dX, X1, (size_t)P * w1 * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(dGX, GX, (size_t)Mp * w1 * 8, hipMemcpyHostToDevice, ctx->st));
+  int f = 0;
+  RET(launch_rbf_contract(ctx, dG, P, Pm, Mp, dZ, dX, w1, dR, dGX, &f));      // the call backward_chunk makes
+  if (fused) *fused = f;
+  HIPCHK(hipMemcpyAsync(R1, dR, (size_t)P * w1 * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipMemcpyAsync(GX, dGX, (size_t)Mp * w1 * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  return DGP_OK;
+}
+
 int dgp_dev_chol(dgp_ctx* ctx, double* A, int32_t M, int32_t batch) {
   if (!ctx || !A || M <= 0 || M % 16 != 0 || batch <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_dev_chol: M must be a multiple of 16");
   double* d;

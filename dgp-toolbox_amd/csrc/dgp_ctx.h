@@ -814,6 +814,28 @@ int launch_Ct_T(dgp_ctx* ctx, GemmArgs aC, GemmArgs aT, const double* Linv, long
   return DGP_OK;
 }
 
+// The two skinny contractions of the RBF backward pass through Kuf: R1 [Pm x w1] = g [Z | 1] and, with GXacc, GXacc [Mp x w1] +=
+// g^T [X | 1].  One pass over g on the matrix cores where points.hip's kernel applies (Mp = 256, D_in <= 8, >= 2048 points), else
+// two products on the 128 x 64 engine.  *fused (may be null): which of the two ran.
+int launch_rbf_contract(dgp_ctx* ctx, const double* Gt, long Pl, long Pm, int Mp, const double* Z1, const double* X1, int w1,
+                        double* R1, double* GXacc, int* fused) {
+  const bool f = rbf_bwd_contract_ok(Mp, w1, Pl);
+  if (fused) *fused = f ? 1 : 0;
+  if (f) {
+    if (GXacc && !ctx->rg_ws) RET(dev_alloc(ctx, &ctx->rg_ws, (size_t)rbf_bwd_contract_ws_doubles()));
+    ProfScope ps(ctx, 0, (GXacc ? 4.0 : 2.0) * Pl * Mp * w1, (double)Pl * Mp * 8);
+    HIPCHK(rbf_bwd_contract(ctx->st, Gt, Pl, Z1, X1, w1, R1, GXacc, ctx->rg_ws));
+    return DGP_OK;
+  }
+  RET(GX(ctx, 0, GEMM_NN, mk(Pm, w1, Mp, Gt, Mp, Z1, w1, R1, w1), 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
+  if (GXacc) {
+    GemmArgs a = mk(Mp, w1, Pl, Gt, Mp, X1, w1, GXacc, w1, 1.0, 1);
+    a.splits = pick_splits(ctx, Mp, w1, Pl);
+    RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
+  }
+  return DGP_OK;
+}
+
 // ------------------------------------------------------------------------------- forward over one chunk
 int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc, int S, uint64_t seed, bool use_zs,
                   long n_goff) {
@@ -984,18 +1006,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
         ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 16);
         HIPCHK(make_x1(ctx->st, Xin, row0, Pl, Din, ctx->X1));
       }
-      if (rbf_bwd_contract_ok(Mp, w1, Pl)) {      // both contractions in one pass over g (points.hip)
-        if (o.params && !ctx->rg_ws) RET(dev_alloc(ctx, &ctx->rg_ws, (size_t)rbf_bwd_contract_ws_doubles()));
-        ProfScope ps(ctx, 0, (o.params ? 4.0 : 2.0) * Pl * Mp * w1, (double)Pl * Mp * 8);
-        HIPCHK(rbf_bwd_contract(ctx->st, ctx->Gt, Pl, y.Z1, ctx->X1, w1, ctx->R1, o.params ? acc + y.acc_GX : nullptr, ctx->rg_ws));
-      } else {
-        RET(GX(ctx, 0, GEMM_NN, mk(Pm, w1, Mp, ctx->Gt, Mp, y.Z1, w1, ctx->R1, w1), 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
-        if (o.params) {
-          GemmArgs a = mk(Mp, w1, Pl, ctx->Gt, Mp, ctx->X1, w1, acc + y.acc_GX, w1, 1.0, 1);
-          a.splits = pick_splits(ctx, Mp, w1, Pl);
-          RET(GX(ctx, 0, GEMM_TN, a, 2.0 * Pl * Mp * w1, (double)Pl * Mp * 8));
-        }
-      }
+      RET(launch_rbf_contract(ctx, ctx->Gt, Pl, Pm, Mp, y.Z1, ctx->X1, w1, ctx->R1, o.params ? acc + y.acc_GX : nullptr, nullptr));
       ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 24);
       HIPCHK(xbar_finish(ctx->st, ctx->R1, ctx->X1, Pl, P(ctx, y.off_ls), Din, D, y.d.mean_kind, y.meanW, y.mbar,
                          (l > 0 || o.xgrad0) ? 1 : 0, ctx->xbar, o.params ? acc + y.acc_x2 : nullptr));

@@ -244,6 +244,13 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t P, int32_t Mp, int32_t D, const
                            const double* Wcat, const double* u, const double* vbar, const double* mbar, double* Ct,
                            double* cn, double* T, double* tn, double* mean0, double* Cbar, double* g, double* du,
                            double* Gd, int32_t* engines);
+/* The two skinny contractions of the backward pass through an RBF / Matern Kuf (what tf.GradientTape derives for Z, the
+ * lengthscales and the layer's inputs through gpflow's K(Z, X): layers.py:243 under dgp.py:272-275), through
+ * the launcher backward_chunk uses:  R1 [P, w1] = G Z1  and  GX [Mp, w1] += G^T X1  (G [P, Mp], Z1 = [Z | 1], X1 = [X | 1], w1 =
+ * D_in + 1).  *fused (may be NULL): 1 when both ran as one pass over G on the matrix cores (Mp = 256, w1 <= 9, P >= 2048), 0 when
+ * as two products on the 128 x 64 engine. */
+int dgp_dev_rbf_contract(dgp_ctx* ctx, const double* G, const double* Z1, const double* X1, int64_t P, int32_t Mp, int32_t w1,
+                         double* R1, double* GX /* in/out */, int32_t* fused);
 int dgp_dev_chol(dgp_ctx* ctx, double* A, int32_t M, int32_t batch);            /* in place, lower */
 int dgp_dev_trinv(dgp_ctx* ctx, const double* L, double* X, int32_t M, int32_t batch);
 int dgp_dev_normals(dgp_ctx* ctx, uint64_t seed, int32_t layer, int32_t S, int64_t n0, int64_t N, int32_t D,

@@ -224,3 +224,24 @@ def test_half_row_launches_forced_at_small_sizes():
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("P,Mp,w1,fused", [(101760, 256, 9, True), (12496, 256, 9, True), (2048 + 5, 256, 2, True), (40000, 256, 4, True),
+                                           (2000, 256, 9, False), (30000, 512, 9, False), (5000, 256, 12, False)])
+def test_rbf_backward_contractions_against_numpy(ctx, P, Mp, w1, fused):
+    """R1 = g [Z | 1] (every row: the x-gradient of a stationary kernel) and GX += g^T [X | 1] (the Z / lengthscale gradients),
+    through the launcher the backward pass uses, against NumPy: the one-pass matrix-core kernel of points.hip where it applies
+    (asserted), the two engine products elsewhere; a ragged last 16-point tile and a pre-filled GX included.
+    Reference: what tf.GradientTape derives through gpflow's K(Z, X) (R/dgp_dace/utils/layers.py:243, R/dgp_dace/models/dgp.py:272-275)."""
+    rng = np.random.default_rng(P + Mp + w1)
+    G = rng.standard_normal((P, Mp)); Z1 = rng.standard_normal((Mp, w1)); X1 = rng.standard_normal((P, w1))
+    GX0 = rng.standard_normal((Mp, w1))
+    R1, GX, f = ctx.dev_rbf_contract(G, Z1, X1, GX0)
+    assert f == fused
+    ref = G @ Z1
+    assert np.abs(R1 - ref).max() <= 1e-12 * np.abs(ref).max()
+    ref = GX0 + G.T @ X1
+    assert np.abs(GX - ref).max() <= 1e-12 * np.abs(ref).max()
+    if fused:                                                            # no atomics there: two runs agree to the bit
+        R1b, GXb, _ = ctx.dev_rbf_contract(G, Z1, X1, GX0)
+        assert np.array_equal(R1, R1b) and np.array_equal(GX, GXb)
