@@ -915,7 +915,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     const long Pl = dedup ? Nc : (long)S * Nc, Pm = pad_rows(Pl);
     const double* Xin = dedup ? o.X : ctx->L[l - 1].F;
     const long row0 = dedup ? n0 : 0;
-    const long DM = (long)D * Mp, MM = (long)Mp * Mp;
+    const long DM = (long)D * Mp;
     const double tri1 = (double)Pl * Mp * (Mp + 1.0);
     if (small_fused(ctx, y) && y.Tt) {
       // at most 64 inducing points: dC, g, g^T [Z | 1] and [X | 1] in one launch, the four sums over the points in a second
