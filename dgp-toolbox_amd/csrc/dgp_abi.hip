@@ -952,9 +952,16 @@ int dgp_adam_iterations(dgp_ctx* ctx, int32_t n_iter, int32_t S, uint64_t seed0,
   // Measured on MI355X / ROCm 7.2 (tools/small_model_bench.py): the replayed graph is SLOWER than the call-by-call
   // launches (config 1: 0.81 against 0.75 ms per iteration; notebook model 0.90 against 0.77) -- the replay runs the
   // captured side-stream branches one after the other, and these iterations are bound by the dependent chain of ~85
-  // kernels of 4-15 us, not by the host's launch rate.  So -1 ("by size") currently means "no"; 1 or DGP_GRAPH=1 asks
-  // for the graph.
+  // kernels of 4-15 us, not by the host's launch rate.  That was round 2.  With the fused small-layer kernels (round 3: ~21
+  // launches per iteration) the replay wins where the iteration has no side-stream branches to speak of - one hidden layer:
+  // config 1 0.381 against 0.404 ms, nat-adam 0.96 against 1.05 - and still loses with two hidden layers (notebook model 0.48
+  // against 0.43: three chains that the replay runs one after the other).  -1 ("by size") therefore means: models of at most two
+  // SVGP layers whose layers all run on the fused small-layer kernels; 1 or DGP_GRAPH=1 asks for the graph, 0 / DGP_GRAPH=0 refuses.
   bool graph = use_graph > 0;
+  if (use_graph < 0 && nl <= 2) {
+    graph = true;
+    for (int l = 0; l < nl; ++l) graph = graph && small_fused(ctx, ctx->L[l]) && ctx->L[l].off_white < 0;
+  }
   {
     static int env = -2;
     if (env == -2) { const char* e = getenv("DGP_GRAPH"); env = e ? atoi(e) : -1; }

@@ -192,8 +192,8 @@ int dgp_adam_step(dgp_ctx* ctx, double lr, double beta_1, double beta_2, double 
  * step on the layers of layer_mask) in ONE call.  Evaluation k of the call draws its normals with seed0 + k (one
  * evaluation per iteration, two with gamma > 0).  elbo_out (host, [n_iter], may be NULL): the ELBO each iteration would
  * print.  use_graph = 1: one captured hipGraph is replayed per iteration (seed and Adam step count then live in device
- * memory); 0: call by call; -1: the library decides (today: call by call -- the replay measured slower on launch-bound
- * models, see the implementation).
+ * memory); 0: call by call; -1: the library decides (the graph for models of at most two SVGP layers that run on the fused
+ * small-layer kernels, where the replay measured faster; call by call otherwise -- see the implementation).
  * Results are those of the call-by-call sequence dgp_grad_step / dgp_adam_step (/ dgp_grad_step / dgp_natgrad_step).   */
 int dgp_adam_iterations(dgp_ctx* ctx, int32_t n_iter, int32_t S, uint64_t seed0, double lr, double beta_1, double beta_2,
                         double epsilon, const uint8_t* trainable, double gamma, const uint8_t* layer_mask,
