@@ -245,3 +245,19 @@ def test_rbf_backward_contractions_against_numpy(ctx, P, Mp, w1, fused):
     if fused:                                                            # no atomics there: two runs agree to the bit
         R1b, GXb, _ = ctx.dev_rbf_contract(G, Z1, X1, GX0)
         assert np.array_equal(R1, R1b) and np.array_equal(GX, GXb)
+
+
+@pytest.mark.parametrize("rows", [12544, 8192, 32768])
+def test_gemm_triangular_row_panels_at_shard_sizes(ctx, rows):
+    """Row-panel products with a triangular 256-column B at the row counts of a rank's share of 8 GPUs / the deduplicated first
+    layer (below the wide- and tall-tile kernels' limits: the 128 x 64 engine with its triangular k-range skips): both triangle
+    orientations, one and several k blocks, against NumPy."""
+    rng = np.random.default_rng(rows)
+    L = np.tril(rng.standard_normal((256, 256)))
+    Kt = rng.standard_normal((rows, 256))
+    assert _rel(ctx.dev_gemm("NT", Kt, L, tri=1, triblk=256), Kt @ L.T) < 1e-13          # B = L^T upper
+    assert _rel(ctx.dev_gemm("NN", Kt, L, tri=2, triblk=256), Kt @ L) < 1e-13            # B lower
+    W = [np.tril(rng.standard_normal((256, 256))) for _ in range(3)]
+    T = rng.standard_normal((rows, 3 * 256))
+    Wcat = np.concatenate(W, axis=1)
+    assert _rel(ctx.dev_gemm("NT", T, Wcat, tri=1, triblk=256), T @ Wcat.T) < 1e-13      # sum_d T_d W_d^T: K = 3 blocks
