@@ -40,6 +40,8 @@ int dgp_create(int device, void* hip_stream, dgp_ctx** out) {
     ctx->chain_on = ch && ch[0] == '1';
     const char* dg = getenv("DGP_DU_IN_GRAM");
     ctx->du_in_gram = !(dg && dg[0] == '0');
+    const char* qg = getenv("DGP_Q_FROM_G");
+    ctx->q_from_g = !(qg && qg[0] == '0');
     const char* bt = getenv("DGP_BLOCKED_T");
     ctx->blocked_t = !(bt && bt[0] == '0');
     bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -547,6 +549,13 @@ static int finish_layer_launches(dgp_ctx* ctx, size_t li) {
       GemmArgs a = mk(Mp, Mp, Mp, Gd, Mp, y.Wcat, DM, dW, DM, 2.0, 0);
       a.batch = D; a.sA = MM; a.sB = Mp; a.sC = Mp;
       RET(GX(ctx, 2, GEMM_NN, a));
+    }
+    if (q_from_sums(ctx, y)) {
+      // Q' = u du^T + sum_d (W_d dW_d^T - 2 G_d) from the DATA terms of du and dW (before the KL terms join them below): the
+      // reduction over the points that used to deliver it (a Gram launch reading Cbar and Ct: 1.05 ms per 10^6 points) is gone.
+      // (y.dLq is free until the q_sqrt gradient is written into it further down: it holds the D products dW_d W_d^T meanwhile)
+      RET(G(ctx, 2, GEMM_NT, Mp, Mp, Mp, dW, DM, y.Wcat, DM, y.dLq, Mp, 1.0, 0, D, Mp, Mp, MM));
+      HIPCHK(qprime_from_sums(ctx->st, y.dLq, Gd, y.u, du, Mp, D, Q));
     }
     HIPCHK(wbar_total(ctx->st, dW, y.Wcat, du, y.u, M, Mp, D));
     if (y.d.kernel_kind != DGP_KERNEL_MF) {

@@ -140,6 +140,7 @@ struct dgp_ctx {
   // chain contains a launch that cannot be recorded and runs launch by launch
   struct ChainProg { ChainOp* dev = nullptr; int n = 0; };
   std::map<long, ChainProg> chains;
+  bool q_from_g = true;     // Q' = sum_p cbar_p c_p^T from G_d, du and W in the finish chain instead of a pass over the points (q_from_sums below); DGP_Q_FROM_G=0: the Gram launch
   bool du_in_gram = true;   // du = Ct^T mbar inside the Gram launch of G_d (gemm_gram.h, form DU); DGP_DU_IN_GRAM=0: a launch of its own
   bool chain_on = false;    // off: measured slower than launch by launch (NOTES.md, round 3); DGP_CHAIN=1 enables
   bool prep_deferred = false, prep_deferred_train = false;   // the upper layers' prep chains are still to be enqueued (prep_deferred_layers)
@@ -730,6 +731,14 @@ ZSource zsrc_of(dgp_ctx* ctx, int l, bool use_zs, uint64_t seed, long n_goff, lo
   return z;
 }
 
+// Q' (the Cholesky factor's cotangent through c = Lu^-1 k) is not reduced over the points for this layer: it follows from the
+// layer's other sums (optim.hip: qprime_from_sums).  Not for the composite kernel (its Q is dK^T C, reduced directly) and not on
+// the fused small-layer path (whose one sums kernel produces Q' beside the rest).
+bool q_from_sums(dgp_ctx* ctx, const Layer& y) {
+  // (nor under DGP_CHAIN=1: the assembly kernel is not one of the recordable chain bodies)
+  return ctx->q_from_g && !ctx->chain_on && y.d.kernel_kind != DGP_KERNEL_MF && !(small_fused(ctx, y) && y.Tt);
+}
+
 // ------------------------------------------------------------------------------- the layer's point contractions
 // Their GemmArgs are built in ONE place: forward_chunk / backward_chunk and the unit hook dgp_dev_layer_products (which the
 // tests compare element by element with NumPy at sizes where the wide-tile and tall-tile kernels are selected) issue
@@ -1029,7 +1038,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       if (du_in_gram) { a.gram_mb = y.mbar; a.gram_du = acc + y.acc_du; }
       RET(GX(ctx, 0, GEMM_TN, a, tri1 * D + (du_in_gram ? 2.0 * Pl * Mp * D : 0.0), (double)Pl * Mp * 8));
     }
-    {
+    if (!q_from_sums(ctx, y)) {
       // Q' = Cbar^T C (stationary kernels; Q = Linv^T Q' in finish_layer) or Q = dK^T C (composite kernel: dK is stored)
       GemmArgs a = mk(Mp, Mp, Pl, y.d.kernel_kind != DGP_KERNEL_MF ? ctx->Cbar : ctx->Kbar, Mp, y.Ct, Mp, acc + y.acc_Q, Mp, 1.0, 1);
       a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp), Pl, (long)Mp * 16);

@@ -76,6 +76,35 @@ hipError_t finish_tail_launch(hipStream_t st, const double* acc, double* scal, d
   return hipGetLastError();
 }
 
+// Q' = sum_p cbar_p c_p^T without a pass over the points.  With cbar = u mbar + sum_d 2 vbar_d (W_d W_d^T - I) c (SURVEY App. C
+// step 3):  Q' = u du^T + sum_d (W_d dW_d^T - 2 G_d),  du = sum_p c_p mbar_p^T,  G_d = sum_p vbar_pd c_p c_p^T (symmetric),  dW_d =
+// 2 G_d W_d - all of them already on hand when a layer's gradient is finished (the DATA terms, before the KL terms join).
+// T[d] = dW_d W_d^T arrives as a batched product; this writes  Q'[i][j] = sum_d (u[i][d] du[j][d] + T[d][j][i] - 2 G[d][i][j]),
+// the d terms in order (no atomics: reproducible).
+__global__ void qprime_from_sums_kernel(const double* __restrict__ T, const double* __restrict__ G, const double* __restrict__ u,
+                                        const double* __restrict__ du, int Mp, int D, double* __restrict__ Q) {
+  __shared__ double tile[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const long MM = (long)Mp * Mp;
+  for (int d = 0; d < D; ++d) {
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = T[d * MM + (long)(bj * 32 + r) * Mp + bi * 32 + tx];    // T[d] tile (bj, bi)
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+      const int r = ty + 8 * q;
+      const long i = bi * 32 + r, j = bj * 32 + tx;
+      acc[q] += u[i * D + d] * du[j * D + d] + tile[tx][r] - 2.0 * G[d * MM + i * Mp + j];
+    }
+  }
+  for (int q = 0; q < 4; ++q) Q[(long)(bi * 32 + ty + 8 * q) * Mp + bj * 32 + tx] = acc[q];
+}
+hipError_t qprime_from_sums(hipStream_t st, const double* T, const double* G, const double* u, const double* du, int Mp, int D,
+                            double* Q) {
+  hipLaunchKernelGGL(qprime_from_sums_kernel, dim3((unsigned)(Mp / 32), (unsigned)(Mp / 32)), dim3(256), 0, st, T, G, u, du, Mp, D, Q);
+  return hipGetLastError();
+}
+
 __global__ void iter_bump_kernel(double* it, int seed_inc, int t_inc) {
   uint64_t* seed = reinterpret_cast<uint64_t*>(it);
   seed[0] += (uint64_t)seed_inc;
