@@ -55,13 +55,15 @@ def synthetic(N, D, M, seed=0):
 
 
 def alg_flops_step(N, S, dims, M, Dy):
-    """Algorithmic flops of one iteration as built (triangular products, first layer once per data point):
-    per layer and point (1 + D_out) * M(M+1) forward, twice that backward."""
+    """Algorithmic flops of one iteration as built (triangular products, first layer once per data point): per layer and point
+    (1 + D_out) * M(M+1) forward (c, t_d) and (2 D_out + 1) * M(M+1) backward (dC from the stored t_d, dK, G_d).  The fourth
+    backward product of rounds 1-2, Q' = sum_p cbar_p c_p^T, is no longer a pass over the points (it follows from G_d, du and W in
+    the finish chain) and is no longer counted."""
     total = 0.0
     douts = dims[1:] + [Dy]
     for l, dout in enumerate(douts):
         P = N if l == 0 else N * S
-        total += 3.0 * P * (1 + dout) * M * (M + 1.0)
+        total += P * (3.0 * dout + 2.0) * M * (M + 1.0)
     return total
 
 

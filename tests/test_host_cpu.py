@@ -236,7 +236,8 @@ def test_infill_host_math_without_a_device():
 
 def test_bench_flop_accounting_matches_the_survey_tables():
     """bench.py's roofline numerators: SURVEY §8d's own count reproduces its table (config 2: 4.631e12, 2-alt:
-    2.620e12); the executed-formulation count credits the first layer once and one triangular solve."""
+    2.620e12); the executed-formulation count credits the first layer once, one triangular solve and
+    the three backward products that are passes over the points (Q' is assembled from the layer's other sums)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
@@ -245,7 +246,7 @@ def test_bench_flop_accounting_matches_the_survey_tables():
     assert abs(bench.survey_flops_step(100_000, 10, [8, 8], 256, 1) / 2.620e12 - 1) < 1e-3
     assert abs(bench.survey_flops_step(1_000_000, 10, [16, 16, 16, 16], 512, 1) / 4.542e14 - 1) < 1e-3
     ours = bench.alg_flops_step(100_000, 10, [8, 8, 8], 256, 1)
-    want = 3.0 * 256 * 257 * (100_000 * 9 + 1_000_000 * 9 + 1_000_000 * 2)
+    want = 256 * 257 * (100_000 * 26.0 + 1_000_000 * 26.0 + 1_000_000 * 5.0)      # (3 D_out + 2) M (M + 1) per point and layer
     assert abs(ours / want - 1) < 1e-12 and ours < bench.survey_flops_step(100_000, 10, [8, 8, 8], 256, 1)
     X, Y, Z = bench.synthetic(1000, 3, 16)
     assert X.shape == (1000, 3) and Y.shape == (1000, 1) and Z.shape == (16, 3)
