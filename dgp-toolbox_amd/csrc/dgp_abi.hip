@@ -559,7 +559,7 @@ static int finish_layer_launches(dgp_ctx* ctx, size_t li) {
     }
     HIPCHK(wbar_total(ctx->st, dW, y.Wcat, du, y.u, M, Mp, D));
     if (y.d.kernel_kind != DGP_KERNEL_MF) {
-      // the reduction over the points delivered Q' = Cbar^T C (lower triangle): Q = dK^T C = Linv^T Q'.  Row i >= column j
+      // Q' = Cbar^T C (assembled above, or its lower triangle reduced over the points): Q = dK^T C = Linv^T Q'.  Row i >= column j
       // of the product only meets Q'[k][j] with k >= i >= j (Linv is lower triangular): the lower triangle suffices
       RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Linv, Mp, Q, Mp, ctx->sm[6], Mp, 1.0, 0));
       HIPCHK(copy_mat(ctx->st, ctx->sm[6], Q, MM));

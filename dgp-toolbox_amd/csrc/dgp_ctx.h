@@ -969,7 +969,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
     // ---- from here the layer's work splits into two independent parts that only read dC:
     //   B (HBM-bound, no matrix-core time to speak of): g = dK .* k, the two skinny contractions of g, the x-gradient, the
     //     fold into the layer below, du = Ct^T mbar - 6 GB + 3 x 2 GB of streaming per 10^6 points;
-    //   A (matrix-core bound): the reductions over the points G_d and Q'.
+    //   A (matrix-core bound): the reductions over the points G_d (and Q' where it is still reduced: q_from_sums).
     // With `overlap_b` they run side by side: B on the context's low-priority stream, A on the main stream with R CUs left
     // free by its persistent one-workgroup-per-CU kernels (GemmArgs::reserve_cus; a workgroup of those fills its CU, so
     // without the reservation B would only start when A ends).  The main stream rejoins B before it leaves the layer
@@ -1039,6 +1039,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       RET(GX(ctx, 0, GEMM_TN, a, tri1 * D + (du_in_gram ? 2.0 * Pl * Mp * D : 0.0), (double)Pl * Mp * 8));
     }
     if (!q_from_sums(ctx, y)) {
+      // (only where Q' is not assembled from the layer's other sums: q_from_sums)
       // Q' = Cbar^T C (stationary kernels; Q = Linv^T Q' in finish_layer) or Q = dK^T C (composite kernel: dK is stored)
       GemmArgs a = mk(Mp, Mp, Pl, y.d.kernel_kind != DGP_KERNEL_MF ? ctx->Cbar : ctx->Kbar, Mp, y.Ct, Mp, acc + y.acc_Q, Mp, 1.0, 1);
       a.tri = TRI_OUT_LOWER; a.triblk = Mp; a.splits = pick_splits_tiles(ctx, lower_tiles(Mp), Pl, (long)Mp * 16);
