@@ -566,13 +566,14 @@ static int finish_layer_launches(dgp_ctx* ctx, size_t li) {
     }
     if (y.kdot) HIPCHK(lower_dot(ctx->st, y.Lu, Q, M, Mp, y.kdot));      // before Q is overwritten below
     if (!y.d.white) {
-      RET(G(ctx, 2, GEMM_NT, Mp, Mp, D, du, D, y.u, D, T1, Mp, 1.0, 0));
-      // K = D*Mp against an Mp x Mp output: split the reduction so that more than a handful of workgroups run
+      // T1 = du u^T + sum_d dW_d W_d^T (K = D Mp against an Mp x Mp output)
       if (Mp <= 64) {      // small models: D accumulating one-workgroup products (recordable as chain steps, fixed order)
+        RET(G(ctx, 2, GEMM_NT, Mp, Mp, D, du, D, y.u, D, T1, Mp, 1.0, 0));
         for (int d = 0; d < D; ++d)
           RET(G(ctx, 2, GEMM_NT, Mp, Mp, Mp, dW + (long)d * Mp, DM, y.Wcat + (long)d * Mp, DM, T1, Mp, 1.0, 1));
-      } else {
-        RET(G(ctx, 2, GEMM_NT, Mp, Mp, DM, dW, DM, y.Wcat, DM, T1, Mp, 1.0, 1, 1, 0, 0, 0, D > 1 ? D : 1));
+      } else {             // one batched Mp^3 product into the still unused dLq buffer, then the sum over d in order (optim.hip)
+        RET(G(ctx, 2, GEMM_NT, Mp, Mp, Mp, dW, DM, y.Wcat, DM, y.dLq, Mp, 1.0, 0, D, Mp, Mp, MM));
+        HIPCHK(sum_dprod(ctx->st, y.dLq, du, y.u, Mp, D, T1));
       }
       RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Linv, Mp, T1, Mp, T2, Mp, 1.0, 0));
       RET(G(ctx, 2, GEMM_TN, Mp, Mp, Mp, y.Linv, Mp, dW, DM, y.dLq, Mp, 1.0, 0, D, 0, Mp, MM));

@@ -99,6 +99,25 @@ __global__ void qprime_from_sums_kernel(const double* __restrict__ T, const doub
   }
   for (int q = 0; q < 4; ++q) Q[(long)(bi * 32 + ty + 8 * q) * Mp + bj * 32 + tx] = acc[q];
 }
+// out[i][j] = sum_d (a[i][d] b[j][d] + T[d][i][j]): the K = D Mp product  a b^T + sum_d dW_d W_d^T  of the finish chain as ONE
+// batched Mp^3 product (T[d] = dW_d W_d^T, 32 x 32-tile kernel) plus this sum over d, in order - instead of a split-K launch of the
+// 128 x 64 engine that added its D partial products with atomics (35 us, and an order that changed from run to run)
+__global__ void sum_dprod_kernel(const double* __restrict__ T, const double* __restrict__ a, const double* __restrict__ b, int Mp, int D,
+                                 double* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long MM = (long)Mp * Mp;
+  if (idx >= MM) return;
+  const int i = (int)(idx / Mp), j = (int)(idx % Mp);
+  double acc = 0.0;
+  for (int d = 0; d < D; ++d) acc += a[i * D + d] * b[j * D + d] + T[d * MM + idx];
+  out[idx] = acc;
+}
+hipError_t sum_dprod(hipStream_t st, const double* T, const double* a, const double* b, int Mp, int D, double* out) {
+  const long MM = (long)Mp * Mp;
+  hipLaunchKernelGGL(sum_dprod_kernel, dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st, T, a, b, Mp, D, out);
+  return hipGetLastError();
+}
+
 hipError_t qprime_from_sums(hipStream_t st, const double* T, const double* G, const double* u, const double* du, int Mp, int D,
                             double* Q) {
   hipLaunchKernelGGL(qprime_from_sums_kernel, dim3((unsigned)(Mp / 32), (unsigned)(Mp / 32)), dim3(256), 0, st, T, G, u, du, Mp, D, Q);
