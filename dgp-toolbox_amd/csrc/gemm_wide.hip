@@ -15,7 +15,10 @@ bool gemm_wide_ok(const GemmArgs& a) {
   // one workgroup per CU walks the tiles: fewer than a few rounds of tiles leave CUs idle (small models, the deduplicated
   // first layer of a small shard): those stay on the 128 x 64 engine with its four times finer tiles
   static long min_tiles = -1;
-  if (min_tiles < 0) { const char* e = getenv("DGP_WIDE_MIN_TILES"); min_tiles = e ? atol(e) : 768; }
+  // (768 until round 3 - three rounds of tiles; measured on the shards of a strongly-scaled run: a 25 008-point first layer (196
+  //  tiles, one workgroup on 196 of 256 CUs) already runs Ct / dC faster here than on the engine: N/4 14.74 -> 14.52 ms, N/2 25.83
+  //  -> 25.40 ms; a 12 496-point one (98 tiles) does not: 8.62 -> 9.01 ms)
+  if (min_tiles < 0) { const char* e = getenv("DGP_WIDE_MIN_TILES"); min_tiles = e ? atol(e) : 192; }
   if ((a.M / WBM) * (a.N / WBN) < min_tiles) return false;
   if (a.M <= 0 || a.M % WBM != 0 || a.N <= 0 || a.N % WBN != 0 || a.K <= 0 || a.K % WBK != 0) return false;
   if (a.batch > 1 || a.splits > 1 || a.beta != 0) return false;

@@ -100,8 +100,8 @@ def test_weighted_gram_kernel_against_numpy(ctx, P, D):
         assert np.abs(g1[0] - ref)[lower].max() <= 1e-12 * np.abs(ref).max()
 
 
-# (P, Mp, D, kernel families expected for Ct / T / dC).  The wide-tile kernel takes a row-panel product from 768 tiles of
-# 128 x 256 on (csrc/gemm_wide.hip): `Ct` and `dC` (256 columns) from 98 304 rows, `T` from 98 304 / D rows; the tall-tile
+# (P, Mp, D, kernel families expected for Ct / T / dC [/ du / G_d]).  The wide-tile kernel takes a row-panel product from 192
+# tiles of 128 x 256 on (csrc/gemm_wide.hip): `Ct` and `dC` (256 columns) from 24 576 rows, `T` from 24 576 / D rows; the tall-tile
 # kernels (Mp = 256) replace its `T` / `dC` modes.  98 432 = 769 x 128 rows: the last 256-row tile is half empty.
 PRODUCTION_CASES = [
     (98304 + 128, 256, 8, ("wide", "tall", "tallu", "gram", "gram")),        # (du rides on G_d's Gram launch)
@@ -109,6 +109,7 @@ PRODUCTION_CASES = [
     (98304 + 384, 256, 3, ("wide", "tall", "tallu", "gram", "gram")),
     (49152 + 128, 512, 2, ("wide", "wide", "wide")),          # BASELINE config 4's inducing count
     (20000, 256, 8, ("engine128x64", "tall", "engine128x64")),   # below the limits of Ct / dC (157 tiles): the 128 x 64 engine, padded rows; T (1256 tiles) is eligible on its own
+    (25008, 256, 8, ("wide", "tall", "tallu", "gram", "gram")),   # one rank's share of 4: the first layer's shape (196 tiles of Ct)
     (12496, 256, 8, ("engine128x64", "tall", "engine128x64")),   # one rank's share of 8: the first layer's shape
     (12496, 256, 1, ("engine128x64", "engine128x64", "engine128x64")),
     (3001, 192, 2, ("engine128x64", "engine128x64", "engine128x64")),
