@@ -223,7 +223,10 @@ def main():
             "config": {"workload": f"DGP num_units={num_units} ({len(num_units) + 1} SVGP layers), N={args.N}, "
                                    f"D={args.D}, M={args.M}, S={args.S}, " + (f"minibatch {args.minibatch}" if args.minibatch else "full batch") + ", optimize_adam iteration",
                        "N": args.N, "D": args.D, "M": args.M, "S": args.S, "num_units": num_units,
-                       "parallelism": f"data points sharded over {world} GPU(s), one all-reduce per layer and iteration, overlapped with the backward pass"},
+                       "parallelism": (f"data points sharded over {world} GPU(s), " +
+                                       ("one all-reduce per layer and iteration under the backward pass (library-owned RCCL communicator)"
+                                        if os.environ.get("DGP_COMM", "torch") == "native" else
+                                        "one all-reduce of the partial-sum buffer per iteration (process group's collective) before the replicated small-matrix chains and Adam"))},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_tallu_kernel + dgp::gemm_gram_kernel + dgp::gemm_f64_kernel (all point contractions, rank 0)",
