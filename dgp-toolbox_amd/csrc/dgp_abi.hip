@@ -1,6 +1,8 @@
 // libdgp_hip.so: the C-ABI of the SVGP-layer ELBO path (include/dgp_abi.h) on top of dgp_ctx.h.
 #include "dgp_ctx.h"
 #include <dlfcn.h>
+#include <link.h>
+#include <limits.h>
 
 struct ncclUniqueIdBytes { char internal[128]; };   // rccl.h: ncclUniqueId (passed by value to ncclCommInitRank)
 
@@ -705,6 +707,54 @@ int nccl_chk(dgp_ctx* ctx, int rc, const char* what) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------- one ROCm stack per process
+// A process that holds two copies of libamdhip64 (torch's wheel ships one with the system ROCm's soname and asks for it by
+// file name) hands one stack's streams and buffers to the other's RCCL in dgp_comm_init ("unhandled cuda error") and aborts
+// at exit (double free).  Nothing used to detect that state (NOTES 12.3); these do.
+namespace {
+struct RuntimeScan { std::vector<std::string> paths; };
+int runtime_scan_cb(struct dl_phdr_info* info, size_t, void* data) {
+  const char* nm = info->dlpi_name;
+  if (!nm || !*nm) return 0;
+  const char* base = strrchr(nm, '/');
+  base = base ? base + 1 : nm;
+  if (strncmp(base, "libamdhip64.so", 14) != 0) return 0;
+  auto* sc = static_cast<RuntimeScan*>(data);
+  char real[PATH_MAX];
+  std::string p = realpath(nm, real) ? std::string(real) : std::string(nm);
+  for (const std::string& q : sc->paths)
+    if (q == p) return 0;
+  sc->paths.push_back(p);
+  return 0;
+}
+}  // namespace
+
+int dgp_hip_runtimes(char* paths_out, int cap) {
+  RuntimeScan sc;
+  dl_iterate_phdr(runtime_scan_cb, &sc);
+  if (paths_out && cap > 0) {
+    std::string joined;
+    for (size_t i = 0; i < sc.paths.size(); ++i) joined += (i ? "\n" : "") + sc.paths[i];
+    snprintf(paths_out, (size_t)cap, "%s", joined.c_str());
+  }
+  return (int)sc.paths.size();
+}
+
+namespace {
+int one_runtime_or_fail(dgp_ctx* ctx, const char* who) {
+  char paths[2048];
+  const int n = dgp_hip_runtimes(paths, (int)sizeof paths);
+  if (n <= 1) return DGP_OK;
+  for (char* c = paths; *c; ++c)
+    if (*c == '\n') *c = ' ';
+  char msg[2400];
+  snprintf(msg, sizeof msg,
+           "%s: %d copies of libamdhip64 are mapped in this process (%s): import torch BEFORE loading libdgp_hip.so so that "
+           "both use one ROCm stack", who, n, paths);
+  return fail(ctx, DGP_ERR_INVALID, msg);
+}
+}  // namespace
+
 int dgp_comm_available(void) { return nccl_load(nullptr); }
 
 int dgp_comm_unique_id(void* id128_out) {
@@ -721,6 +771,7 @@ int dgp_comm_init(dgp_ctx* ctx, int32_t rank, int32_t world, const void* id128) 
   if (world == 1 && !id128) return DGP_OK;      // single process: nothing to reduce
   if (!id128) return fail(ctx, DGP_ERR_INVALID, "dgp_comm_init: no unique id");
   // (world == 1 WITH an id builds a one-rank communicator: the whole RCCL path can then be exercised on one GPU)
+  RET(one_runtime_or_fail(ctx, "dgp_comm_init"));
   RET(nccl_load(ctx));
   HIPCHK(hipSetDevice(ctx->device));
   ncclUniqueIdBytes id;

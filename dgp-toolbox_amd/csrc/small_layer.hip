@@ -853,21 +853,31 @@ hipError_t small_natgrad(hipStream_t st, double* Lq, const double* dLq, const do
   return hipGetLastError();
 }
 
+// LDS of the per-point kernels: the layer's (1 + D) matrices + the waves' vectors; above 64 KB the kernels' limit has to be
+// raised (hipFuncSetAttribute) - per DEVICE (the attribute belongs to the device's copy of the function), and a refusal
+// makes the fused path unavailable there (small_layer_ok false -> the layer runs on the general kernels) instead of an
+// opaque launch failure later.
+static size_t sl_point_lds(int D) { return (size_t)((1 + D) * SL_M * SL_M + 4 * SL_Q * SL_M) * 8; }
+static bool sl_lds_limit_raised() {
+  constexpr int kMaxDev = 64;
+  static signed char state[kMaxDev];            // 0 unknown, 1 raised, -1 refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return false;
+  if (state[dev] == 0) {
+    const int want = (int)sl_point_lds(SL_MAXD);
+    const bool ok =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(small_layer_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(small_layer_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    state[dev] = ok ? 1 : -1;
+  }
+  return state[dev] > 0;
+}
+
 bool small_layer_ok(int kind, int Mp, int D, int Din) {
   static int enabled = -1;
   if (enabled < 0) { const char* e = getenv("DGP_SMALL_FUSED"); enabled = e ? atoi(e) : 1; }
-  return enabled && kind >= 0 && kind <= 2 && Mp == SL_M && D >= 1 && D <= SL_MAXD && Din >= 1 && Din <= 32;
-}
-
-// LDS of the per-point kernels: the layer's (1 + D) matrices + the waves' vectors; above 64 KB the kernel's limit is raised
-// once (hipFuncSetAttribute)
-static size_t sl_point_lds(int D) { return (size_t)((1 + D) * SL_M * SL_M + 4 * SL_Q * SL_M) * 8; }
-static void sl_raise_lds_limit() {
-  static bool done = false;
-  if (done) return;
-  done = true;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_layer_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl_point_lds(SL_MAXD));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_layer_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl_point_lds(SL_MAXD));
+  return enabled && kind >= 0 && kind <= 2 && Mp == SL_M && D >= 1 && D <= SL_MAXD && Din >= 1 && Din <= 32 && sl_lds_limit_raised();
 }
 
 hipError_t small_layer_fwd(hipStream_t st, int kind, const double* Xin, long P, long x_row0, int Din, const double* Z,
@@ -875,7 +885,7 @@ hipError_t small_layer_fwd(hipStream_t st, int kind, const double* Xin, long P, 
                            const double* u, double* Kt, double* Et, double* Ct, double* Tt, double* cn, double* tn,
                            long pstride, double* mean0) {
   if (P <= 0) return hipSuccess;
-  sl_raise_lds_limit();
+  if (!sl_lds_limit_raised()) return hipErrorInvalidValue;
   const int ppb = pts_per_block_for(P);
   hipLaunchKernelGGL(small_layer_fwd_kernel, dim3((unsigned)((P + ppb - 1) / ppb)), dim3(256), sl_point_lds(D), st, kind, Xin, P, x_row0, Din, Z,
                      var, ls, M, D, LinvT, Wcat, u, Kt, Et, Ct, Tt, cn, tn, pstride, mean0, ppb);
@@ -887,7 +897,7 @@ hipError_t small_layer_bwd(hipStream_t st, const double* Xin, long P, long x_row
                            const double* Ek, const double* vbar, const double* mbar, double* Cbar, double* Gt, double* R1,
                            double* X1) {
   if (P <= 0) return hipSuccess;
-  sl_raise_lds_limit();
+  if (!sl_lds_limit_raised()) return hipErrorInvalidValue;
   const int ppb = pts_per_block_for(P);
   hipLaunchKernelGGL(small_layer_bwd_kernel, dim3((unsigned)((P + ppb - 1) / ppb)), dim3(256), sl_point_lds(D), st, Xin, P, x_row0, Din, D, Linv,
                      Scat, u, Z1, Ct, Tt, Ek, vbar, mbar, Cbar, Gt, R1, X1, ppb);

@@ -19,7 +19,7 @@ DGP_OK, ERR_INVALID, ERR_HIP, ERR_NOT_PD, ERR_NO_DEVICE, ERR_NONFINITE = 0, -1, 
 
 # every symbol include/dgp_abi.h declares
 SYMBOLS = [
-    "dgp_create", "dgp_destroy", "dgp_last_error", "dgp_sync", "dgp_device_info", "dgp_model_set", "dgp_param_count",
+    "dgp_create", "dgp_destroy", "dgp_last_error", "dgp_sync", "dgp_device_info", "dgp_hip_runtimes", "dgp_model_set", "dgp_param_count",
     "dgp_params_get", "dgp_params_set", "dgp_data_set", "dgp_set_workspace_limit", "dgp_batch_set", "dgp_elbo", "dgp_propagate",
     "dgp_propagate_vjp", "dgp_vjp_accumulate", "dgp_propagate_full_cov", "dgp_gpr_lml", "dgp_gpr_predict", "dgp_gpr_predict_vjp",
     "dgp_grad_partial", "dgp_acc_info", "dgp_acc_bind", "dgp_grad_finish", "dgp_grad_get", "dgp_last_elbo", "dgp_grad_step",
@@ -73,6 +73,41 @@ def _one_hip_runtime():
         pass
 
 
+def hip_runtimes_in(mapped_paths):
+    """Distinct copies of libamdhip64 among the paths of a process's mapped objects (the lines of /proc/self/maps, or what
+    dl_iterate_phdr reports): one entry per real file.  More than one = two ROCm stacks in the process (see
+    `_one_hip_runtime`)."""
+    seen = []
+    for line in mapped_paths:
+        path = line.split()[-1] if line.split() else ""
+        if not path.startswith("/") or not os.path.basename(path).startswith("libamdhip64.so"):
+            continue
+        real = os.path.realpath(path) if os.path.exists(path) else path
+        if real not in seen:
+            seen.append(real)
+    return seen
+
+
+def check_one_hip_runtime(paths=None):
+    """Raise NativeUnavailable naming the copies when more than one libamdhip64 is mapped (DGP_ALLOW_TWO_RUNTIMES=1 turns
+    the refusal into a warning; `dgp_comm_init` refuses regardless).  `paths`: a list to judge instead of this process."""
+    if paths is None:
+        buf = C.create_string_buffer(4096)
+        n = _lib.dgp_hip_runtimes(buf, len(buf)) if _lib is not None else 0
+        paths = buf.value.decode().split("\n") if n else []
+    paths = hip_runtimes_in(paths)
+    if len(paths) <= 1:
+        return paths
+    msg = (f"{len(paths)} copies of libamdhip64 are mapped in this process ({', '.join(paths)}): two ROCm stacks. "
+           "`import torch` BEFORE the first use of dgp_dace (or never import it, with DGP_HIP_RUNTIME=system) so that "
+           "libdgp_hip.so and torch share one; mixing them ends in `ncclCommInitRank: unhandled cuda error` or an abort at exit.")
+    if os.environ.get("DGP_ALLOW_TWO_RUNTIMES", "0") == "1":
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=2)
+        return paths
+    raise NativeUnavailable(msg)
+
+
 def load():
     """Load the shared library (no device is touched)."""
     global _lib
@@ -91,6 +126,7 @@ def load():
         "dgp_last_error": (C.c_char_p, [vp]),
         "dgp_sync": (C.c_int, [vp]),
         "dgp_device_info": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(i64)]),
+        "dgp_hip_runtimes": (C.c_int, [C.c_char_p, C.c_int]),
         "dgp_model_set": (C.c_int, [vp, C.c_int, C.POINTER(LayerDesc), _dp, i64, _dp, i64]),
         "dgp_param_count": (i64, [vp]),
         "dgp_params_get": (C.c_int, [vp, _dp]),
@@ -140,6 +176,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     _lib = lib
+    check_one_hip_runtime()
     return lib
 
 
@@ -162,6 +199,7 @@ class Context:
 
     def __init__(self, device=0, stream=None):
         lib = load()
+        check_one_hip_runtime()        # a later `import torch` may have brought a second ROCm stack in since load()
         h = C.c_void_p()
         rc = lib.dgp_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
         if rc == ERR_NO_DEVICE:

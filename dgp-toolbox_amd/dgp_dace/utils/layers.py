@@ -105,10 +105,22 @@ class SVGP_Layer(Layer):
         return [as_tensor(np.reshape(m, (S, N, self.num_outputs))) for m in (mean, var)]
 
     def sample_from_conditional(self, X, z=None, full_cov=False):
-        mean, var = self.conditional_SND(X, full_cov=full_cov)
+        """layers.py:87-130.  full_cov=True draws through the Cholesky factor of `var + jitter I` per (sample, output)
+        (utils.py:43-51) on the device: one `dgp_propagate_full_cov` call per sample, each with its own inputs."""
+        X = np.asarray(X, dtype=np.float64)
+        S, N, _ = X.shape
         if z is None:
-            z = np.random.standard_normal(mean.shape)
-        return as_tensor(mean + np.asarray(z) * (var + JITTER) ** 0.5), mean, var
+            z = np.random.standard_normal((S, N, self.num_outputs))
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        if z.shape != (S, N, self.num_outputs):
+            raise ValueError(f"z must be [S, N, D_out] = {(S, N, self.num_outputs)}, got {z.shape}")
+        if full_cov:
+            ctx = self._ctx()
+            Fs, Fm, Fv = zip(*[[a[0][0] for a in ctx.propagate_full_cov(np.ascontiguousarray(X[s]), 1, 0, [z[s:s + 1]])]
+                               for s in range(S)])
+            return as_tensor(np.stack(Fs)), as_tensor(np.stack(Fm)), as_tensor(np.stack(Fv))
+        mean, var = self.conditional_SND(X, full_cov=False)
+        return as_tensor(mean + z * (var + JITTER) ** 0.5), mean, var
 
     def KL(self):
         ctx = self._ctx()

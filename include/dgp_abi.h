@@ -62,6 +62,10 @@ void dgp_destroy(dgp_ctx* ctx);
 const char* dgp_last_error(const dgp_ctx* ctx);
 int dgp_sync(dgp_ctx* ctx);                 /* hipStreamSynchronize + deferred error flags */
 int dgp_device_info(dgp_ctx* ctx, char* name_out, int name_len, int* cu_count, int64_t* hbm_bytes);
+/* How many distinct copies of libamdhip64 are mapped in this process (dl_iterate_phdr), their paths newline-separated in
+ * `paths_out`.  More than one = two ROCm stacks (torch's wheel ships its own under the system's soname): dgp_comm_init then
+ * refuses with DGP_ERR_INVALID naming both, and the ctypes binding refuses to create a context.  No device is touched.  */
+int dgp_hip_runtimes(char* paths_out, int cap);
 
 /* ---- model: replaces DGP.__init__ / init_layers_linear / SVGP_Layer.__init__ state
  *      (dgp.py:245-254, layer_initializations.py:24-68, layers.py:181-224).

@@ -27,6 +27,97 @@ def test_notebook_known_answer_on_gpu():
     assert m.name == "dgp"
 
 
+def test_bo_notebook_known_answer_through_so_bo(capsys):
+    """nb_dgp_BO.ipynb cells 5-6, 14-15, 18, 30 (and 61): `SO_BO(problem, DoE_size=5, model_Y_dic, model_C_dic,
+    normalize_input=True).train_models(...)` prints `ELBO: -73.6722504558447` as the first line of the constraint model's
+    `optimize_nat_adam` (SO_BO.py:248,258; dgp.py:323-333).  The value is independent of the (unseeded, unstored) DoE and
+    of z; it is taken after the q_sqrt * 1e-3 scaling, i.e. at q != prior in the two inner layers (non-white KL,
+    layers.py:293-300).  Same closed form and the oracle's reproduction: tests/test_oracle.py::test_bo_notebook_known_answer."""
+    from dgp_dace.BO.SO_BO import SO_BO
+
+    class Constrained_problem(object):
+        def __init__(self):
+            self.constraint = True
+            self.dim = 1
+        def fun(self, x):
+            return [(x - 0.5) ** 2, np.where(x > 0.25, 1.0, 0.0)]
+
+    for seed in (1, 3):
+        bo = SO_BO(Constrained_problem(), DoE_size=5, model_Y_dic={'num_layers': 0, 'kernels': 'rbf'},
+                   model_C_dic={'num_layers': 2, 'num_units': 1, 'kernels': 'rbf', 'num_samples': 10},
+                   normalize_input=True, seed=seed)
+        assert 0 < bo.C.sum() < 5 and bo.model_C[0].name == 'dgp' and len(bo.model_C[0].layers) == 3
+        capsys.readouterr()
+        bo.train_models(iteration_Y=5, iteration_C=2)       # SO_BO.train_model: iterations1=500 is fixed (SO_BO.py:258)
+        out = capsys.readouterr().out.splitlines()
+        assert out[0] == 'Training of the objective function model' and out[1] == 'Training of constraint model 1'
+        printed = [float(l.split("ELBO:")[1]) for l in out if l.startswith("ELBO:")]
+        assert len(printed) == 5 + 1                          # steps 0, 100, ..., 400 of part 1; step 0 of part 2
+        assert abs(printed[0] - (-73.6722504558447)) < 1e-9, printed[0]
+        assert printed[-1] > printed[0] and np.all(np.isfinite(printed))
+
+
+def test_config1_stated_shape_against_oracle(capsys):
+    """BASELINE.json configs[0] at its stated shape: `num_units=[1]` -> 2 SVGP layers, N = 1000, D = 1,
+    M = 32, S = 10, the synthetic data of bench.py.  ELBO and every gradient block against the oracle (torch-autograd twin)
+    with the same Philox normals, then the printed ELBOs of `optimize_nat_adam(iterations1=2, iterations2=2)` (one part-2
+    iteration = 2 evaluations + Adam + natural gradient, dgp.py:337-345) against the oracle's trainer."""
+    import os
+    import sys
+    import dgp_oracle_torch as T
+    from dgp_oracle_train import OracleTrainer
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    N, D, M, S = 1000, 1, 32, 10
+    X, Y, Z = synthetic(N, D, M)
+    m = DGP(X, Y, Z, [RBF(1.0, [1.0]) for _ in range(2)], [1], Gaussian(), num_samples=S, seed=11)
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(1.0, [1.0]) for _ in range(2)], [1], num_samples=S)
+    assert len(m.layers) == 2 and m.layers[0].q_mu.shape == (M, 1)
+    # (1) pristine state: z-independent closed form (last layer at the prior)
+    closed = float(np.sum(-0.5 * np.log(2 * np.pi) - 0.5 * (Y ** 2 + 1.0)))
+    assert abs(m.ELBO() - closed) < 1e-9 * abs(closed)
+    # (2) a non-trivial state: every term of the bound and every gradient block is live
+    rng = np.random.default_rng(5)
+    for l, lo in zip(m.layers, mo.layers):
+        qm = 0.3 * rng.standard_normal((M, 1))
+        qs = lo.q_sqrt * 0.2 + 0.01 * np.tril(rng.standard_normal((1, M, M)))
+        ls, var = np.array([0.8]), 1.3
+        l.q_mu.assign(qm); lo.q_mu = qm.copy()
+        l.q_sqrt.assign(qs); lo.q_sqrt = qs.copy()
+        l.kern.lengthscales.assign(ls); lo.kern.lengthscales = ls.copy()
+        l.kern.variance.assign(var); lo.kern.variance = var
+    m.likelihood.likelihood.variance.assign(0.4); mo.lik_variance = 0.4
+    ctx = m._sync_model()
+    m._sync_data(m.data)
+    ctx.grad_partial(S, 9, None)
+    elbo = ctx.grad_finish(want_elbo=True)
+    eo, G = T.elbo_and_grads(mo, O.draw_zs(mo, 9, S, N))
+    assert abs(elbo - eo) < 1e-9 * abs(eo), (elbo, eo)
+    Gp = split_flat(m, ctx.grad_get())
+    for i in range(2):
+        for k in ("Z", "lengthscales", "variance", "q_mu", "q_sqrt"):
+            ref = np.asarray(G["layers"][i][k])
+            got = np.tril(Gp[(i, k)]) if k == "q_sqrt" else Gp[(i, k)]
+            assert np.abs(got - ref).max() < 1e-7 * max(1.0, np.abs(ref).max()), (i, k)
+    assert abs(Gp[("lik", "variance")] - G["lik_variance"]) < 1e-7 * max(1.0, abs(G["lik_variance"]))
+    # (3) the trainer: 2 Adam iterations + 2 part-2 iterations from a fresh model, printed ELBOs against the oracle's
+    m = DGP(X, Y, Z, [RBF(1.0, [1.0]) for _ in range(2)], [1], Gaussian(), num_samples=S, seed=11)
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(1.0, [1.0]) for _ in range(2)], [1], num_samples=S)
+    capsys.readouterr()
+    m.optimize_nat_adam(iterations1=2, iterations2=2, lr_adam=0.01, lr_gamma=0.01, beta_1=0.8, beta_2=0.9, messages=1)
+    printed = [float(l.split("ELBO:")[1]) for l in capsys.readouterr().out.splitlines() if l.startswith("ELBO:")]
+    ref = OracleTrainer(mo, base_seed=11).optimize_nat_adam(2, 2, lr_adam=0.01, lr_gamma=0.01, beta_1=0.8, beta_2=0.9)
+    assert len(printed) == 4
+    assert abs(printed[0] - ref[0]) < 1e-9 * abs(ref[0])
+    _close(printed, ref, rtol=1e-6)
+    for l, lo in zip(m.layers, mo.layers):
+        _close(l.q_mu.numpy(), lo.q_mu, rtol=1e-5, atol=1e-6 * max(1e-3, np.abs(lo.q_mu).max()))
+        _close(l.q_sqrt.numpy(), lo.q_sqrt, rtol=1e-5, atol=1e-6 * np.abs(lo.q_sqrt).max())
+        _close(l.kern.lengthscales.numpy(), lo.kern.lengthscales, rtol=1e-6)
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_propagate_elbo_predict_match_golden(case):
     g = load(case)

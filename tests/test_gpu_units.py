@@ -262,3 +262,57 @@ def test_gemm_triangular_row_panels_at_shard_sizes(ctx, rows):
     T = rng.standard_normal((rows, 3 * 256))
     Wcat = np.concatenate(W, axis=1)
     assert _rel(ctx.dev_gemm("NT", T, Wcat, tri=1, triblk=256), T @ Wcat.T) < 1e-13      # sum_d T_d W_d^T: K = 3 blocks
+
+
+@pytest.mark.parametrize("white", [False, True])
+def test_layer_api_conditionals_samples_and_kl_against_the_oracle_layer(white):
+    """The per-layer surface of the reference (`SVGP_Layer.conditional_ND / conditional_SND / sample_from_conditional / KL`,
+    layers.py:63-130,237-308) evaluated through a one-layer device context, against `OracleLayer` in the same state;
+    `sample_from_conditional(full_cov=True)` must draw through chol(var + jitter I) per (sample, output) (utils.py:43-51)."""
+    import dgp_oracle as O
+    from dgp_dace.gpflow_compat import RBF, Identity
+    from dgp_dace.utils.layers import SVGP_Layer
+    rng = np.random.default_rng(12)
+    M, Din, Dout, S, N = 20, 3, 3, 2, 17
+    Z = rng.standard_normal((M, Din))
+    ls, var = np.array([0.9, 1.2, 0.7]), 1.4
+    lay = SVGP_Layer(RBF(var, ls), Z, Dout, Identity(), white=white)
+    ora = O.OracleLayer(O.RBF(var, ls), Z, Dout, O.MeanFunction("identity"), white=white)
+    q_mu = 0.5 * rng.standard_normal((M, Dout))
+    q_sqrt = np.tril(0.3 * np.asarray(lay.q_sqrt.numpy()) + 0.05 * rng.standard_normal((Dout, M, M)))
+    lay.q_mu.assign(q_mu); lay.q_sqrt.assign(q_sqrt)
+    ora.q_mu, ora.q_sqrt = q_mu.copy(), q_sqrt.copy()
+    X = rng.standard_normal((S, N, Din))
+    z = rng.standard_normal((S, N, Dout))
+    for full_cov in (False, True):
+        f, mean, v = lay.sample_from_conditional(X, z=z, full_cov=full_cov)
+        fo, mo, vo = ora.sample_from_conditional(X, z, full_cov=full_cov)
+        assert np.asarray(v).shape == ((S, N, N, Dout) if full_cov else (S, N, Dout))
+        np.testing.assert_allclose(np.asarray(mean), mo, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(np.asarray(v), vo, rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(np.asarray(f), fo, rtol=1e-7, atol=1e-8)
+    # the full-covariance draw is not the diagonal formula (what this method computed before round 4)
+    _, mo, vo = ora.conditional_SND(X, full_cov=True)
+    diag_form = mo + z * (np.einsum("snnd->snd", vo) + 1e-6) ** 0.5
+    f, _, _ = lay.sample_from_conditional(X, z=z, full_cov=True)
+    assert np.abs(np.asarray(f) - diag_form).max() > 1e-3
+    m1, v1 = lay.conditional_ND(X[0])
+    mo1, vo1 = ora.conditional_ND(X[0])
+    np.testing.assert_allclose(np.asarray(m1), mo1, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(np.asarray(v1), vo1, rtol=1e-8, atol=1e-9)
+    assert abs(lay.KL() - ora.KL()) < 1e-8 * max(1.0, abs(ora.KL()))
+    assert np.asarray(lay.sample_from_conditional(X)[0]).shape == (S, N, Dout)      # z drawn when not supplied
+    with pytest.raises(ValueError):
+        lay.sample_from_conditional(X, z=z[:, :-1])
+
+
+def test_one_rocm_stack_in_the_normal_load_order(ctx):
+    """torch first, then the library (what dgp_dace._native.load does): exactly one libamdhip64 is mapped, also after
+    torch.cuda has been initialised, so dgp_comm_init's refusal of a two-stack process stays silent (the one-rank
+    communicator tests of test_gpu_parity.py go through it)."""
+    import torch
+    from dgp_dace import _native
+    assert torch.cuda.is_available() and torch.zeros(1, device="cuda").item() == 0.0
+    paths = _native.check_one_hip_runtime()
+    assert len(paths) == 1, paths
+    assert paths == _native.hip_runtimes_in(open("/proc/self/maps"))

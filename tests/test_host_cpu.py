@@ -113,6 +113,35 @@ def test_library_exports_every_symbol_declared_in_the_header():
         assert hasattr(lib, s), s
 
 
+def test_two_rocm_stacks_in_one_process_are_detected(monkeypatch):
+    """NOTES 12.3 / VERDICT r3 weak #4: torch's wheel ships a libamdhip64 under the system ROCm's soname; a process holding
+    both hands one stack's streams to the other's RCCL.  The detector on a fake map list, and on this process."""
+    from dgp_dace import _native
+    one = ["7f00-7f10 r-xp 0 00:00 1  /usr/lib/python3/site-packages/torch/lib/libamdhip64.so",
+           "7f20-7f30 r--p 0 00:00 1  /usr/lib/python3/site-packages/torch/lib/libamdhip64.so",
+           "7f40-7f50 r-xp 0 00:00 2  /usr/lib/python3/site-packages/torch/lib/librccl.so",
+           "7f60-7f70 rw-p 0 00:00 0  [heap]", ""]
+    assert _native.hip_runtimes_in(one) == ["/usr/lib/python3/site-packages/torch/lib/libamdhip64.so"]
+    assert _native.check_one_hip_runtime(one) == _native.hip_runtimes_in(one)
+    two = one + ["7f80-7f90 r-xp 0 00:00 3  /opt/rocm-7.2.0/lib/libamdhip64.so.7.2.70200"]
+    assert len(_native.hip_runtimes_in(two)) == 2
+    with pytest.raises(_native.NativeUnavailable) as e:
+        _native.check_one_hip_runtime(two)
+    assert "torch/lib/libamdhip64.so" in str(e.value) and "/opt/rocm-7.2.0/lib/libamdhip64.so.7.2.70200" in str(e.value)
+    monkeypatch.setenv("DGP_ALLOW_TWO_RUNTIMES", "1")
+    with pytest.warns(RuntimeWarning):
+        assert len(_native.check_one_hip_runtime(two)) == 2
+    monkeypatch.delenv("DGP_ALLOW_TWO_RUNTIMES")
+    # this process, through the library's own scan (dl_iterate_phdr): the binding imported torch first -> one stack,
+    # and it agrees with /proc/self/maps
+    lib = _native.load()
+    buf = ctypes.create_string_buffer(4096)
+    n = lib.dgp_hip_runtimes(buf, len(buf))
+    assert n == 1, buf.value
+    assert _native.hip_runtimes_in(buf.value.decode().split("\n")) == _native.hip_runtimes_in(open("/proc/self/maps"))
+    assert _native.check_one_hip_runtime() == _native.hip_runtimes_in(open("/proc/self/maps"))
+
+
 def test_no_cpu_fallback_without_a_device():
     """On a machine without a GPU the hot path must fail loudly (it never routes through the oracle)."""
     import torch
