@@ -1,0 +1,115 @@
+// Attribution harness for the tall-tile kernels: the forward T product as built (blocked stores with
+// the nontemporal hint), with plain stores, and with the stores removed (row sums only), the backward dC product and the
+// weighted Gram kernel, each launched `reps` times back to back on 10^6 rows (steady power state).  Run it plain for the
+// event-timed durations, or under `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace`
+// (clock = GRBM_GUI_ACTIVE / duration; issue share = MFMA busy / (4 SIMDs x CUs x active cycles)).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I dgp-toolbox_amd/csrc tools/tall_bench.hip \
+//         dgp-toolbox_amd/csrc/gemm_f64.hip dgp-toolbox_amd/csrc/gemm_wide.hip dgp-toolbox_amd/csrc/gemm_gram.hip \
+//         dgp-toolbox_amd/csrc/gemm_tall.hip dgp-toolbox_amd/csrc/gemm_tallu.hip dgp-toolbox_amd/csrc/gemm_small.hip \
+//         dgp-toolbox_amd/csrc/gemm_mid.hip -o tools/tall_bench
+//   tools/tall_bench [rows] [reps] [D] [which: bitmask 1 T/NT, 2 T/plain, 4 T/no store, 8 dC, 16 Gram]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+#include <functional>
+#include "gemm_tall.h"
+#include "gemm_tallu.h"
+using namespace dgp;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static double* dalloc(size_t n) { double* p; CK(hipMalloc(&p, n * 8)); return p; }
+static void fill_rand(double* d, size_t n, unsigned seed, double scale = 1.0) {
+  std::vector<double> h(1 << 22);
+  srand(seed);
+  for (auto& x : h) x = scale * ((double)rand() / RAND_MAX - 0.5);
+  for (size_t off = 0; off < n; off += h.size()) CK(hipMemcpy(d + off, h.data(), std::min(h.size(), n - off) * 8, hipMemcpyHostToDevice));
+}
+static void fill_tri_blocks(double* d, long rows, long cols, bool lower, unsigned seed) {   // 256 x 256 triangular blocks
+  std::vector<double> h((size_t)rows * cols);
+  srand(seed);
+  for (long r = 0; r < rows; ++r)
+    for (long c = 0; c < cols; ++c) {
+      const long rr = r % 256, cc = c % 256;
+      const bool keep = lower ? cc <= rr : cc >= rr;
+      h[(size_t)r * cols + c] = keep ? ((double)rand() / RAND_MAX - 0.5) : 0.0;
+    }
+  CK(hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+}
+static float time_ms(hipStream_t st, int reps, const std::function<void()>& f) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  f(); f(); CK(hipStreamSynchronize(st));
+  CK(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) f();
+  CK(hipEventRecord(e1, st));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / reps;
+}
+
+int main(int argc, char** argv) {
+  const long P = ((argc > 1 ? atol(argv[1]) : 1000000) + 255) / 256 * 256;
+  const int reps = argc > 2 ? atoi(argv[2]) : 10;
+  const int D = argc > 3 ? atoi(argv[3]) : 8;
+  const int which = argc > 4 ? atoi(argv[4]) : 31;
+  hipStream_t st; CK(hipStreamCreate(&st));
+  int cus = 256; CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+  const long DM = 256L * D;
+  double* Ct = dalloc((size_t)P * 256); fill_rand(Ct, (size_t)P * 256, 1);
+  double* T = dalloc((size_t)P * DM); fill_rand(T, (size_t)P * DM, 2);
+  double* W = dalloc(256 * DM); fill_tri_blocks(W, 256, DM, true, 3);
+  double* WT = dalloc(DM * 256); fill_tri_blocks(WT, DM, 256, false, 4);
+  double* rs = dalloc((size_t)2 * D * P);
+  double* vbar = dalloc((size_t)P * D); fill_rand(vbar, (size_t)P * D, 5);
+  double* mbar = dalloc((size_t)P * D); fill_rand(mbar, (size_t)P * D, 6);
+  double* u = dalloc(256 * D); fill_rand(u, 256 * D, 7);
+  double* Cb = dalloc((size_t)P * 256);
+  double* G = dalloc((size_t)D * 65536); CK(hipMemset(G, 0, (size_t)D * 65536 * 8));
+  double* ws = dalloc(gemm_gram_ws_bytes(0) / 8);
+  const double flopsT = (double)P * D * 256.0 * 257.0;
+
+  TallArgs g{};
+  g.A = Ct; g.lda = 256; g.B = W; g.ldb = DM; g.C = T; g.ldc = DM; g.rowsq = rs; g.rowsq_ld = P; g.M = P; g.D = D;
+  const long ntile = ((P + 255) / 256) * D;
+  const unsigned gridT = (unsigned)std::min<long>(ntile, cus);
+  printf("rows %ld, D %d, %d CUs, %d launches per variant\n", P, D, cus, reps);
+  if (which & 1) {
+    const float t = time_ms(st, reps, [&]() { hipLaunchKernelGGL((gemm_tall_kernel<true, true>), dim3(gridT), dim3(512), 0, st, g); });
+    printf("T  = Ct W   blocked stores, nontemporal   %8.3f ms  %5.1f TFLOP/s algorithmic\n", t, flopsT / t / 1e9);
+  }
+  if (which & 2) {
+    const float t = time_ms(st, reps, [&]() { hipLaunchKernelGGL((gemm_tall_kernel<true, false>), dim3(gridT), dim3(512), 0, st, g); });
+    printf("T  = Ct W   blocked stores, plain         %8.3f ms  %5.1f TFLOP/s algorithmic\n", t, flopsT / t / 1e9);
+  }
+  if (which & 4) {
+    TallArgs n = g; n.C = nullptr;
+    const float t = time_ms(st, reps, [&]() { hipLaunchKernelGGL((gemm_tall_kernel<false, false>), dim3(gridT), dim3(512), 0, st, n); });
+    printf("T  = Ct W   row sums only (no stores)     %8.3f ms  %5.1f TFLOP/s algorithmic\n", t, flopsT / t / 1e9);
+  }
+  if (which & 8) {
+    TallUArgs a{};
+    a.A = T; a.lda = DM; a.B = WT; a.ldb = 256; a.C = Cb; a.ldc = 256; a.s = vbar; a.as_ld = D; a.eadd = Ct; a.rowf = mbar; a.colf = u;
+    a.rank = D; a.alpha = 2.0; a.M = P; a.D = D;
+    const unsigned gridU = (unsigned)std::min<long>((P + 255) / 256, cus);
+    float t;
+    if (D == 8) t = time_ms(st, reps, [&]() { hipLaunchKernelGGL(gemm_tallu_kernel<8>, dim3(gridU), dim3(512), 0, st, a); });
+    else t = time_ms(st, reps, [&]() { hipLaunchKernelGGL(gemm_tallu_kernel<-1>, dim3(gridU), dim3(512), 0, st, a); });
+    printf("dC = [2v.T] WT - (s2v) Ct + mbar uT       %8.3f ms  %5.1f TFLOP/s algorithmic\n", t, flopsT / t / 1e9);
+  }
+  if (which & 16) {
+    GemmArgs a{};
+    a.gram_ws = ws; a.gram_ws_bytes = gemm_gram_ws_bytes(0);
+    a.A = Ct; a.B = Ct; a.C = G; a.lda = a.ldb = a.ldc = 256; a.M = a.N = 256; a.K = P; a.batch = D; a.sC = 65536;
+    a.alpha = 1.0; a.beta = 1; a.tri = TRI_OUT_LOWER; a.triblk = 256; a.splits = 1; a.ascale = vbar; a.as_ld = D; a.ascale_mode = 2;
+    if (!gemm_gram_ok(a)) printf("Gram: not eligible\n");
+    else {
+      const float t = time_ms(st, reps, [&]() { CK(gemm_f64(st, GEMM_TN, a)); });
+      printf("G_d = sum_p v_pd c_p c_pT (Gram kernel)   %8.3f ms  %5.1f TFLOP/s algorithmic\n", t, flopsT / t / 1e9);
+    }
+  }
+  CK(hipDeviceSynchronize());
+  return 0;
+}
