@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--minibatch", type=int, default=0,
                     help="points per iteration over all ranks (0 = full batch, the headline configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nat-steps", type=int, default=10,
+                    help="after the timed Adam region: this many part-2 iterations of optimize_nat_adam (2 evaluations + Adam + "
+                         "natural gradient, dgp.py:337-345), timed the same way and reported as extra keys (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=8192)
     args = ap.parse_args()
 
@@ -151,6 +154,8 @@ def main():
     #   DGP_BENCH_ONE_RANK_COMM=1  a one-rank library-owned RCCL communicator attached (DGP_COMM=native's path: per-layer
     #                              all-reduce on the comm stream, persistent kernels leave 8 CUs free)
     bench_path = os.environ.get("DGP_BENCH_PATH", "step")
+    if world == 1 and bench_path == "partial":
+        ctx.acc_info()          # as a sharded run does: the transport form of the partial sums (pack / unpack) is part of the rehearsal
     if world == 1 and os.environ.get("DGP_BENCH_ONE_RANK_COMM") == "1":
         from dgp_dace._native import Context
         ctx.comm_init(0, 1, Context.comm_unique_id())
@@ -179,6 +184,8 @@ def main():
     fence()
     log("warm-up done")
     ctx.prof_enable(True)
+    if dist and model._dist is not None:
+        model._dist.timing(True)
     t0 = time.perf_counter()
     ctx.prof_mark()
     for _ in range(args.steps):
@@ -192,10 +199,43 @@ def main():
     ctx.prof_enable(False)
     model._device_newer = True
     med_ms = float(np.median(step_ms)) if len(step_ms) else 1e3 * dt / args.steps
+    ar_ms, ar_bytes = None, None
     if dist:
         dt = model._dist.all_reduce_max(dt, local_rank)
         med_ms = model._dist.all_reduce_max(med_ms, local_rank)
+        ar = model._dist.timing_read()
+        model._dist.timing(False)
+        if ar:                                  # the collective of the default path (three-stage form), event-timed per iteration
+            ar_ms = model._dist.all_reduce_max(float(np.median(ar)), local_rank)
+            ar_bytes = int(model._acc_tensor.numel()) * 8
     elbo_last = ctx.last_elbo()
+
+    # ---- the natural-gradient iteration north_star names (part 2 of optimize_nat_adam, dgp.py:337-345): one Adam step on the
+    # hyper-parameters + one natural-gradient step on every layer's q(u), each behind its own ELBO evaluation with fresh normals
+    nat = None
+    if args.nat_steps > 0:
+        mask = model._natgrad_setup(True)
+        nflags = model._trainable_flags()
+
+        def nat_step():
+            c = model._grad_step(model.data)
+            c.adam_step(0.01, 0.9, 0.999, 1e-7, nflags)
+            c = model._grad_step(model.data)
+            c.natgrad_step(0.01, mask)
+
+        for _ in range(2):
+            nat_step()
+        fence()
+        tn = time.perf_counter()
+        for _ in range(args.nat_steps):
+            nat_step()
+        fence()
+        tn = time.perf_counter() - tn
+        model._device_newer = True
+        if dist:
+            tn = model._dist.all_reduce_max(tn, local_rank)
+        nat = {"ms": 1e3 * tn / args.nat_steps, "elbo": ctx.last_elbo()}
+        log(f"natural-gradient iterations done: {nat['ms']:.2f} ms each")
 
     if rank == 0:
         it_s = args.steps / dt
@@ -238,8 +278,29 @@ def main():
                                                               / world / (mf["ms"] / args.steps * 1e-3) / 1e12
                                                               / FP64_MFMA_PEAK_TFLOPS},
             "breakdown_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+            "breakdown_note": "HIP-event spans per category on the stream each launch was issued on; the small-matrix chains run on side "
+                              "streams BESIDE full-chip persistent kernels, so their spans include waiting for CUs and the categories "
+                              "overlap: the sum exceeds ms_per_step (their own cost is ~0.9 ms per step, profiles/r3_shard_sizes.txt)",
             "elbo_last": elbo_last, "device": name,
         }
+        if nat is not None:
+            flops_it = 2.0 * alg_flops_step(args.minibatch or args.N, args.S, dims, args.M, 1) / world
+            out["nat_adam_ms_per_iteration"] = nat["ms"]
+            out["nat_adam_it_s"] = 1e3 / nat["ms"]
+            out["nat_adam_steps"] = args.nat_steps
+            out["nat_adam_whole_step_frac"] = flops_it / (nat["ms"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS
+            out["nat_adam_note"] = ("part 2 of DGP.optimize_nat_adam (dgp.py:337-345): 2 ELBO evaluations + gradients, Adam on the "
+                                    "hyper-parameters, natural-gradient step (gamma 0.01) on every layer's q(u); timed after the "
+                                    "headline region, same barriers, max over ranks; `value` stays the optimize_adam iteration")
+            out["nat_adam_elbo_last"] = nat["elbo"]
+        if world > 1:
+            native = os.environ.get("DGP_COMM", "torch") == "native" and getattr(model, "_native_comm", False)
+            out["collective"] = ("library-owned RCCL communicator: one ncclAllReduce per layer on the comm stream (dgp_grad_step)" if native else
+                                 f"torch.distributed all_reduce ({dist.get_backend()}) of the packed partial-sum buffer between dgp_grad_partial and dgp_grad_finish")
+            out["allreduce_ms_per_step"] = ar_ms
+            out["allreduce_bytes"] = ar_bytes
+            out["allreduce_note"] = ("median over the timed steps of a HIP-event pair around the collective on the engine's stream (waiting for "
+                                     "the slowest rank included), max over ranks; null under DGP_COMM=native (the collectives are inside the library)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, num_units, X, Y, Z)
             out["elbo_rel_err_vs_oracle"] = out["cpu_baseline"].pop("elbo_rel_err")

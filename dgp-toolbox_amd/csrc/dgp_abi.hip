@@ -517,21 +517,60 @@ int dgp_grad_partial(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const
     RET(backward_chunk(ctx, n0, nc, S, seed, zs != nullptr, BwdOpts{ctx->X, ctx->N, ctx->n_goff, true, false}));
   }
   RET(prep_flush(ctx));            // (no-op unless no chunk ran)
+  if (ctx->xfer_on) {              // a caller reduces the sums over ranks: hand them over in transport form
+    ProfScope ps(ctx, 1, 0, (double)(ctx->n_xfer) * 16);
+    HIPCHK(acc_xfer(ctx->st, ctx->xfer_tab, ctx->n_xfer_seg, ctx->acc, ctx->acc_xfer, false));
+    ctx->xfer_pending = true;
+  }
+  return DGP_OK;
+}
+
+// The transport form of the partial sums (dgp_ctx.h: acc_xfer): segment table + library-owned buffer, built the first time a
+// caller asks for the buffer.  Q' travels only when a layer still reduces it over the points (decided from what is fixed at
+// dgp_model_set time: a layer for which it is assembled behind the reduction never needs it).
+static int xfer_setup(dgp_ctx* ctx) {
+  if (ctx->xfer_tab) return DGP_OK;
+  std::vector<long> tab;
+  long dst = 0;
+  auto seg = [&](long kind, long src, long n) {
+    tab.push_back(kind); tab.push_back(src); tab.push_back(dst); tab.push_back(n);
+    dst += kind ? n * (n + 1) / 2 : n;
+  };
+  seg(0, 0, 4);                                                   // the scalars at the head (ELBO data term, d / d likelihood variance)
+  const int nl = (int)ctx->L.size();
+  for (int l = 0; l < nl; ++l) {
+    const Layer& y = ctx->L[l];
+    const long MM = (long)y.Mp * y.Mp;
+    const bool q_after = ctx->q_from_g && !ctx->chain_on && y.d.kernel_kind != DGP_KERNEL_MF && !small_fused(ctx, y);
+    if (!q_after) seg(0, y.acc_Q, MM);
+    for (int d = 0; d < y.d.D_out; ++d) seg(1, y.acc_G + (long)d * MM, y.Mp);
+    const long end = (l + 1 < nl) ? ctx->L[l + 1].acc_Q : ctx->n_acc;
+    seg(0, y.acc_du, end - y.acc_du);
+  }
+  ctx->n_xfer = dst;
+  ctx->n_xfer_seg = (int)(tab.size() / 4);
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&ctx->xfer_tab), tab.size() * sizeof(long)));
+  HIPCHK(hipMemcpy(ctx->xfer_tab, tab.data(), tab.size() * sizeof(long), hipMemcpyHostToDevice));
+  RET(dev_alloc(ctx, &ctx->acc_xfer_own, dst));
+  HIPCHK(hipMemset(ctx->acc_xfer_own, 0, dst * 8));
+  ctx->acc_xfer = ctx->acc_xfer_own;
   return DGP_OK;
 }
 
 int dgp_acc_info(dgp_ctx* ctx, void** device_ptr, int64_t* n_doubles) {
   if (!ctx || ctx->L.empty()) return fail(ctx, DGP_ERR_INVALID, "dgp_acc_info: no model");
-  if (device_ptr) *device_ptr = ctx->acc;
-  if (n_doubles) *n_doubles = ctx->n_acc;
+  RET(xfer_setup(ctx));
+  ctx->xfer_on = true;                 // from now on dgp_grad_partial ends by packing, dgp_grad_finish starts by unpacking
+  if (device_ptr) *device_ptr = ctx->acc_xfer;
+  if (n_doubles) *n_doubles = ctx->n_xfer;
   return DGP_OK;
 }
 
 int dgp_acc_bind(dgp_ctx* ctx, void* external_device_ptr) {
   if (!ctx || ctx->L.empty()) return fail(ctx, DGP_ERR_INVALID, "dgp_acc_bind: no model");
-  double* acc = external_device_ptr ? reinterpret_cast<double*>(external_device_ptr) : ctx->acc_own;
-  if (acc != ctx->acc) drop_chains(ctx);       // (the buffer's address is part of the recorded finish chains)
-  ctx->acc = acc;
+  RET(xfer_setup(ctx));
+  ctx->xfer_on = true;
+  ctx->acc_xfer = external_device_ptr ? reinterpret_cast<double*>(external_device_ptr) : ctx->acc_xfer_own;
   return DGP_OK;
 }
 
@@ -633,6 +672,11 @@ static int finish_tail(dgp_ctx* ctx) {
 int dgp_grad_finish(dgp_ctx* ctx, double* elbo_out) {
   RET(check_ready(ctx, false));
   HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->xfer_on && ctx->xfer_pending) {     // the (summed) transport buffer of the last dgp_grad_partial back into the working squares
+    ctx->xfer_pending = false;
+    ProfScope ps(ctx, 1, 0, (double)(ctx->n_xfer) * 16);
+    HIPCHK(acc_xfer(ctx->st, ctx->xfer_tab, ctx->n_xfer_seg, ctx->acc, ctx->acc_xfer, true));
+  }
   {
     LayerFork fork(ctx, (int)ctx->L.size());
     for (size_t li = 0; li < ctx->L.size(); ++li) {
@@ -814,7 +858,8 @@ namespace {
 int after_layer_hook(dgp_ctx* ctx, int l, int phase) {
   const int nl = (int)ctx->L.size();
   Layer& y = ctx->L[l];
-  const long lo = y.acc_Q, hi = (l + 1 < nl) ? ctx->L[l + 1].acc_Q : ctx->n_acc;     // the layer's contiguous slice
+  // the layer's contiguous slice; Q' at its head is left out when it is assembled behind the reduction (all zeros until then)
+  const long lo = q_from_sums(ctx, y) ? y.acc_G : y.acc_Q, hi = (l + 1 < nl) ? ctx->L[l + 1].acc_Q : ctx->n_acc;
   const bool comm = ctx->nccl_comm != nullptr;
   const bool side = ctx->use_side && ctx->events_ok && nl <= dgp_ctx::kMaxEv;
   hipStream_t main_st = ctx->st;

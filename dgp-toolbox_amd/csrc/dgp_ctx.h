@@ -91,6 +91,15 @@ struct dgp_ctx {
   long batch_lo = 0, batch_n = 0;   // window of the resident points the bound is evaluated on (batch_n == 0: all of them)
   double data_scale = 1.0;          // factor on the data term (N / batch size for a minibatch estimate)
   double *acc = nullptr, *acc_own = nullptr;
+  // Transport form of the partial-sum buffer (what a multi-GPU host all-reduces: dgp_acc_info / dgp_acc_bind): the lower
+  // triangles of G_d in rectangular packed form, Q' left out when it is assembled after the reduction, everything else
+  // verbatim.  `acc` stays the working (square) buffer; dgp_grad_partial packs into `acc_xfer` at its end, dgp_grad_finish
+  // unpacks at its start.  Active only once a caller asked for the buffer (single-process use never packs).
+  double *acc_xfer = nullptr, *acc_xfer_own = nullptr;
+  long n_xfer = 0;
+  long* xfer_tab = nullptr;     // device: per segment {kind (0 copy, 1 lower triangle), src offset, dst offset, length or Mp}
+  int n_xfer_seg = 0;
+  bool xfer_on = false, xfer_pending = false;
   double *gram_ws = nullptr;                         // partial triangles of the weighted Gram kernel (layers with Mp = 256)
   double *rg_ws = nullptr;                           // per-workgroup GX partials of the one-pass R1 / GX kernel (points.hip: rbf_bwd_contract)
   double *sl_ws = nullptr;                           // per-block partial sums of the fused small-layer backward (small_layer.hip)
@@ -406,7 +415,10 @@ void free_model(dgp_ctx* ctx) {
   ctx->L.clear();
   dev_free(ctx->params); dev_free(ctx->grad); dev_free(ctx->adam_m); dev_free(ctx->adam_v);
   dev_free(ctx->segs_dev); dev_free(ctx->mean_params); dev_free(ctx->acc_own); dev_free(ctx->gram_ws); dev_free(ctx->sl_ws); dev_free(ctx->rg_ws);
+  dev_free(ctx->acc_xfer_own);
+  if (ctx->xfer_tab) { (void)hipFree(ctx->xfer_tab); ctx->xfer_tab = nullptr; }
   ctx->acc = nullptr;
+  ctx->acc_xfer = nullptr; ctx->n_xfer = 0; ctx->n_xfer_seg = 0; ctx->xfer_on = false; ctx->xfer_pending = false;
   for (auto& set : ctx->smset) for (auto& s : set) dev_free(s);
   for (auto& z : ctx->zs_dev) dev_free(z);
   ctx->zs_dev.clear(); ctx->zs_cap.clear();

@@ -47,7 +47,15 @@ constexpr int tl_nact(int p) { return p < 16 ? (p < 7 ? p : 7) + 1 : p - 15; }
 // the stores issued since.  All compile-time: the first pair issues the same (zero) stores as any other.
 constexpr int tl_pre(int p) { return (p <= 6 || (p >= 16 && p <= 22)) ? 4 : 0; }
 constexpr int tl_post(int p) { return (p == 15 || p == 23) ? 4 : 0; }
+#ifdef TL_STORE_AFTER
+// (variant: the deferred stores of a position are issued BEHIND its DMA request, so they are younger than it and the wait two
+//  positions later does not have to see them retired: one more k-tile of slack for the stores of the short ramp k-tiles)
+constexpr int tl_allow(int p) {
+  return 6 + tl_pre((p + 22) % 24) + tl_post((p + 22) % 24) + tl_pre((p + 23) % 24) + tl_post((p + 23) % 24);
+}
+#else
 constexpr int tl_allow(int p) { return 6 + tl_post((p + 22) % 24) + tl_pre((p + 23) % 24) + tl_post((p + 23) % 24); }
+#endif
 
 // NT: the T stores carry the nontemporal hint (cache policy nt): 16 GB per 10^6 rows at D = 8 that nothing re-reads before the
 // backward pass would otherwise stream through the same 4 MB L2 that holds the Ct panel (read by the D pairs of a row tile)
@@ -236,14 +244,23 @@ void gemm_tall_kernel(TallArgs g) {
   nxt = next_of(cons);
   Src scur = src_of(cons.tm, cons.d), snxt = src_of(nxt.tm, nxt.d);
   int stage = 0;
+  unsigned ptm = cons.tm, pd = cons.d;
   issue(std::integral_constant<int, 0>{}, scur, 0);
   issue(std::integral_constant<int, 1>{}, scur, 1);
+#ifdef TL_STORE_AFTER
+  // (what position 22 of a previous pair would have issued behind the request for k-tile 1: zeros into this pair's own left
+  //  half, overwritten at this pair's position 22)
+  flush(std::integral_constant<int, 7>{}, ptm, pd, 0, false);
+#endif
   issue(std::integral_constant<int, 2>{}, scur, 2);
   // the stores a previous pair would have issued behind its last request: zeros into this pair's own right half, which
   // the pair overwrites later (the wave's stores to one address complete in order)
-  unsigned ptm = cons.tm, pd = cons.d;
   flush(std::integral_constant<int, 0>{}, ptm, pd, 1, false);
+#ifdef TL_STORE_AFTER
+  if constexpr (STORE) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#else
   if constexpr (STORE) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#endif
   __builtin_amdgcn_s_barrier();
   readA(0);
   readB(0, uoff(0, 0));
@@ -284,13 +301,17 @@ void gemm_tall_kernel(TallArgs g) {
           readA(0);
           // block column (p % 16) + 1 ... of the tile finished before this one: positions 0..6 (the previous pair's
           // right half, if any) and 16..22 (this pair's left half)
-#ifndef TL_DBG_FLUSHALL
+#if !defined(TL_DBG_FLUSHALL) && !defined(TL_STORE_AFTER)
           if constexpr (p <= 6) flush(std::integral_constant<int, p + 1>{}, ptm, pd, 1, p == 6);
           if constexpr (p >= 16 && p <= 22) flush(std::integral_constant<int, p - 15>{}, cons.tm, cons.d, 0, p == 22);
 #endif
           // the k-tile three ahead: position p + 3 of this pair, or of the workgroup's next pair
           if constexpr (p + 3 < 24) issue(std::integral_constant<int, p + 3>{}, scur, stage);
           else issue(std::integral_constant<int, p + 3 - 24>{}, snxt, stage);
+#if !defined(TL_DBG_FLUSHALL) && defined(TL_STORE_AFTER)
+          if constexpr (p <= 6) flush(std::integral_constant<int, p + 1>{}, ptm, pd, 1, p == 6);
+          if constexpr (p >= 16 && p <= 22) flush(std::integral_constant<int, p - 15>{}, cons.tm, cons.d, 0, p == 22);
+#endif
           stage = stage == TL_NSTAGE - 1 ? 0 : stage + 1;
           __builtin_amdgcn_sched_barrier(0);
         }

@@ -143,4 +143,38 @@ hipError_t iter_log_elbo(hipStream_t st, double* it, const double* scal, double*
   return hipGetLastError();
 }
 
+// ---- transport form of the partial-sum buffer (dgp_ctx.h: acc_xfer).  A lower triangle (diagonal included) of an Mp x Mp
+// matrix, Mp even, in rectangular packed form [Mp / 2][Mp + 1]: row r = row Mp/2 + r of the triangle (Mp/2 + r + 1 entries)
+// followed by row Mp/2 - 1 - r (Mp/2 - r entries) - no square roots, exactly Mp (Mp + 1) / 2 doubles.
+__device__ __forceinline__ void rfp_index(long e, long Mp, long& i, long& j) {
+  const long h = Mp / 2, r = e / (Mp + 1), c = e - r * (Mp + 1);
+  if (c <= h + r) { i = h + r; j = c; }
+  else { i = h - 1 - r; j = c - (h + r + 1); }
+}
+__global__ void acc_xfer_kernel(const long* __restrict__ tab, int nseg, double* __restrict__ sq, double* __restrict__ packed, int unpack) {
+  const long* t = tab + 4L * blockIdx.y;
+  const long kind = t[0], so = t[1], po = t[2], n = t[3];
+  const long count = kind ? n * (n + 1) / 2 : n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
+    if (!kind) {
+      if (unpack) sq[so + e] = packed[po + e]; else packed[po + e] = sq[so + e];
+    } else {
+      long i, j;
+      rfp_index(e, n, i, j);
+      if (unpack) {                 // mirrored: the summed matrices are symmetric, and some consumers read the whole square
+        const double v = packed[po + e];
+        sq[so + i * n + j] = v;
+        sq[so + j * n + i] = v;
+      } else {
+        packed[po + e] = sq[so + i * n + j];
+      }
+    }
+  }
+}
+hipError_t acc_xfer(hipStream_t st, const long* tab, int nseg, double* square, double* packed, bool unpack) {
+  if (nseg <= 0) return hipSuccess;
+  hipLaunchKernelGGL(acc_xfer_kernel, dim3(32, (unsigned)nseg), dim3(256), 0, st, tab, nseg, square, packed, unpack ? 1 : 0);
+  return hipGetLastError();
+}
+
 }  // namespace dgp

@@ -40,6 +40,7 @@ class Dist:
         # (staged through the host), which lets two ranks rehearse the whole path on ONE GPU in tests
         self.on_gpu = dist.get_backend() == "nccl" or (torch.cuda.is_available() and os.environ.get("DGP_DIST_DEVICE", "1") == "1")
         self._stream = None
+        self._timing = None
 
     def local_device(self):
         n = self.torch.cuda.device_count() if self.on_gpu else 1
@@ -74,10 +75,29 @@ class Dist:
         """In-place sum over ranks of the partial-sum buffer (RCCL ring over xGMI on GPUs)."""
         if self._stream is not None:
             with self.torch.cuda.stream(self._stream):
-                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+                if self._timing is not None:       # event pair on the stream the collective is ordered on (bench.py)
+                    e0, e1 = (self.torch.cuda.Event(enable_timing=True) for _ in range(2))
+                    e0.record(self._stream)
+                    self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+                    e1.record(self._stream)
+                    self._timing.append((e0, e1))
+                else:
+                    self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
+
+    def timing(self, on):
+        """Start (True) or stop (False) collecting one HIP-event pair per all-reduce of the partial-sum buffer."""
+        self._timing = [] if on else None
+
+    def timing_read(self):
+        """Milliseconds of every all-reduce since timing(True): from the moment the rank's stream reaches the collective to
+        the moment it may go on, i.e. waiting for the slowest rank included.  Synchronises the stream."""
+        if not self._timing:
+            return []
+        self._stream.synchronize()
+        return [e0.elapsed_time(e1) for e0, e1 in self._timing]
 
     def all_reduce_scalar(self, v, dev=0):
         t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=(f"cuda:{dev}" if self.on_gpu else "cpu"))

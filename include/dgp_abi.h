@@ -153,7 +153,13 @@ int dgp_gpr_predict_vjp(dgp_ctx* ctx, int32_t kernel_kind, const double* X, cons
  *      (dgp.py:270-276, 326-345).  Split so that a multi-GPU host can all-reduce between the stages:
  *   dgp_grad_partial : this rank's sums over its data points (ELBO data term + every point-sum the
  *                      gradient needs) into one contiguous device buffer
- *   dgp_acc_info     : that buffer (device pointer, length in doubles) for an in-place all-reduce
+ *   dgp_acc_info     : that buffer (device pointer, length in doubles) for an in-place all-reduce, in its TRANSPORT form:
+ *                      the lower triangles of the per-output Gram sums G_d in rectangular packed form (Mp (Mp + 1) / 2
+ *                      doubles each), Q' only for layers that still reduce it over the points, every other sum verbatim
+ *                      (config 2: 4.7 MB instead of 10.6 MB of squares).  Calling dgp_acc_info or dgp_acc_bind switches the
+ *                      transport form on: from then on dgp_grad_partial ends by packing into the buffer and dgp_grad_finish
+ *                      starts by unpacking it - so ask for (or bind) the buffer BEFORE dgp_grad_partial.  A context that is
+ *                      never asked (single process) neither packs nor allocates it.
  *   dgp_grad_finish  : small-matrix chain (Cholesky backward, KL gradient) -> d ELBO / d params     */
 int dgp_grad_partial(dgp_ctx* ctx, int32_t S, uint64_t seed, const double* const* zs);
 int dgp_acc_info(dgp_ctx* ctx, void** device_ptr, int64_t* n_doubles);

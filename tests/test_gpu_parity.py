@@ -319,8 +319,8 @@ def test_grad_step_equals_partial_reduce_finish():
     # the three-stage form with the library's communicator between the stages: dgp_grad_partial, dgp_comm_allreduce on the
     # partial-sum buffer (one rank: the identity), dgp_grad_finish
     assert Context.comm_available()
+    ptr, n = ctx.acc_info()                 # (asking for the buffer switches the transport form on: before dgp_grad_partial)
     ctx.grad_partial(int(g["S"]), 0, zs)
-    ptr, n = ctx.acc_info()
     ctx.comm_allreduce(ptr, n)
     e4 = ctx.grad_finish(want_elbo=True)
     assert abs(e4 - e0) <= 1e-13 * abs(e0)
@@ -330,6 +330,79 @@ def test_grad_step_equals_partial_reduce_finish():
         ctx.grad_step(int(g["S"]), 0, zs[:-1])                 # wrong number of injected arrays
     with pytest.raises(ValueError):
         ctx.grad_step(int(g["S"]) + 1, 0, zs)                  # wrong sample count
+
+
+@pytest.mark.parametrize("case", ["case_B_nonwhite", "case_A_white"])
+def test_transport_buffer_packs_triangles_and_sums_over_shards(case):
+    """What a multi-GPU host all-reduces (dgp_acc_info / dgp_acc_bind) is the transport form of the partial sums: lower
+    triangles of G_d in rectangular packed form, Q' left out where it is assembled behind the reduction, the rest verbatim.
+    Emulates two ranks in one process: the sums of two shards (Philox normals keyed by the global point index), added in
+    the bound buffer as an all-reduce would, must give the ELBO and the gradient of the unsharded evaluation."""
+    import torch
+    g = load(case)
+    m = product_from_golden(g, seed=3)
+    S, N = int(g["S"]), g["X"].shape[0]
+    ctx = m._sync_model()
+    m._sync_data(m.data)
+    e0 = ctx.grad_step(S, 17, None, want_elbo=True)
+    g0 = ctx.grad_get()
+    ptr, n = ctx.acc_info()
+    Ms = [int(np.ceil(l.num_inducing / 64.0) * 64) for l in m.layers]
+    full = 4 + sum(Mp * Mp * (1 + l.num_outputs) for Mp, l in zip(Ms, m.layers))
+    tri = 4 + sum(Mp * (Mp + 1) // 2 * l.num_outputs for Mp, l in zip(Ms, m.layers))
+    assert tri < n < full                    # (here Mp = 64, the fused small-layer path: Q' still travels, as a square)
+    # single shard through the transport form: pack + unpack is lossless
+    ctx.grad_partial(S, 17, None)
+    e1 = ctx.grad_finish(want_elbo=True)
+    assert abs(e1 - e0) <= 1e-13 * abs(e0)
+    np.testing.assert_allclose(ctx.grad_get(), g0, rtol=1e-12, atol=1e-12 * np.abs(g0).max())
+    # two shards, summed in a caller-owned buffer
+    t = torch.zeros(n, dtype=torch.float64, device="cuda")
+    ctx.acc_bind(t.data_ptr())
+    X, Y = m.data
+    h = 32
+    ctx.data_set(X[:h], Y[:h], n_global_offset=0)
+    ctx.grad_partial(S, 17, None)
+    ctx.sync()
+    first = t.clone()
+    torch.cuda.synchronize()
+    ctx.data_set(X[h:], Y[h:], n_global_offset=h)
+    ctx.grad_partial(S, 17, None)
+    ctx.sync()
+    assert float(first.abs().max()) > 0 and float(t.abs().max()) > 0
+    t.add_(first)
+    torch.cuda.synchronize()
+    e2 = ctx.grad_finish(want_elbo=True)
+    assert abs(e2 - e0) <= 1e-12 * abs(e0)
+    np.testing.assert_allclose(ctx.grad_get(), g0, rtol=1e-10, atol=1e-11 * np.abs(g0).max())
+    ctx.acc_bind(None)
+    m._data_key = None          # the model's own data were replaced above
+
+
+def test_transport_buffer_size_at_config2_shape():
+    """BASELINE config 2's architecture: the all-reduced buffer is 4.7 MB (triangles, no Q'), not the 10.6 MB of squares."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    X, Y, Z = synthetic(2048, 8, 256)
+    m = DGP(X, Y, Z, [RBF(1.0, np.ones(8)) for _ in range(3)], [8, 8], Gaussian(), num_samples=2)
+    ctx = m._sync_model()
+    _, n = ctx.acc_info()
+    r2 = lambda v: (v + 1) // 2 * 2
+    expect = 4 + sum(D * 256 * 257 // 2 + r2(256 * D) + r2(256 * (8 + 1)) + r2(8) + 2 for D in (8, 8, 1))
+    assert n == expect, (n, expect)
+    assert 4.6e6 < 8 * n < 4.8e6
+    # and the three-stage form on it equals the one-call form (Mp = 256: Gram kernel / engine lower triangles, Q' assembled)
+    m._sync_data(m.data)
+    e0 = ctx.grad_step(2, 5, None, want_elbo=True)
+    g0 = ctx.grad_get()
+    ctx.grad_partial(2, 5, None)
+    e1 = ctx.grad_finish(want_elbo=True)
+    assert abs(e1 - e0) <= 1e-12 * abs(e0)
+    np.testing.assert_allclose(ctx.grad_get(), g0, rtol=1e-10, atol=1e-11 * np.abs(g0).max())
 
 
 @pytest.mark.parametrize("natgrad", [False, True])
@@ -1249,6 +1322,16 @@ def test_bench_py_multi_rank_launch_over_gloo(tmp_path, shape):
         assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and "workload" in d["config"]
         assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1) < 1e-9
     assert abs(d1["elbo_last"] - d2["elbo_last"]) < 1e-10 * abs(d1["elbo_last"])
+    # round 4: the natural-gradient iteration is timed too (extra keys; `value` stays the optimize_adam iteration), and a
+    # multi-rank line says which collective ran, on how many bytes, and what it cost per step
+    for d in (d1, d2):
+        assert d["nat_adam_steps"] == 10 and d["nat_adam_ms_per_iteration"] > d["ms_per_step"] and np.isfinite(d["nat_adam_elbo_last"])
+    assert abs(d1["nat_adam_elbo_last"] - d2["nat_adam_elbo_last"]) < 1e-9 * abs(d1["nat_adam_elbo_last"])
+    assert "collective" not in d1 and "all_reduce (gloo)" in d2["collective"]
+    assert d2["allreduce_ms_per_step"] > 0 and d2["allreduce_bytes"] > 0 and d2["allreduce_bytes"] % 8 == 0
+    M, D = int(shape[1]), int(shape[3])
+    if M == 256:        # triangles of G_d, no Q': (3 layers: D, D, 1 outputs) -- far below the 8 * (1 + D + 1 + D + 1 + 1) * M^2 of squares
+        assert d2["allreduce_bytes"] < 8 * 0.6 * (2 * D + 1) * M * M
 
 
 def test_stationary_plus_white_kernel_in_a_dgp_layer():

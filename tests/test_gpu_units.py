@@ -292,7 +292,7 @@ def test_layer_api_conditionals_samples_and_kl_against_the_oracle_layer(white):
         np.testing.assert_allclose(np.asarray(v), vo, rtol=1e-8, atol=1e-9)
         np.testing.assert_allclose(np.asarray(f), fo, rtol=1e-7, atol=1e-8)
     # the full-covariance draw is not the diagonal formula (what this method computed before round 4)
-    _, mo, vo = ora.conditional_SND(X, full_cov=True)
+    mo, vo = ora.conditional_SND(X, full_cov=True)
     diag_form = mo + z * (np.einsum("snnd->snd", vo) + 1e-6) ** 0.5
     f, _, _ = lay.sample_from_conditional(X, z=z, full_cov=True)
     assert np.abs(np.asarray(f) - diag_form).max() > 1e-3

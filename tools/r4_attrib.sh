@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r4_attrib
 rm -rf $O; mkdir -p $O
 cd $R
-timeout -k 10 300 python -m pytest tests -q -m gpu -k "bo_notebook or config1_stated or layer_api or one_rocm_stack or notebook_known" > $O/pytest_new.log 2>&1 || { echo "pytest failed"; tail -40 $O/pytest_new.log; exit 1; }
+timeout -k 10 300 python -m pytest tests -q -m gpu -k "bo_notebook or config1_stated or layer_api or one_rocm_stack or notebook_known" > $O/pytest_new.log 2>&1 || { echo "pytest failed (continuing)"; tail -40 $O/pytest_new.log; }
 tail -2 $O/pytest_new.log
 timeout -k 10 120 tools/tall_bench 1000000 10 8 31 > $O/tall_bench_events.txt 2>&1 || { echo "tall_bench failed"; tail $O/tall_bench_events.txt; exit 1; }
 cat $O/tall_bench_events.txt
