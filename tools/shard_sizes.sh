@@ -7,6 +7,6 @@ for n in 100000 50000 25008 12496; do
     env=""
     [ $mode = comm1 ] && export DGP_BENCH_ONE_RANK_COMM=1 || unset DGP_BENCH_ONE_RANK_COMM
     [ $mode = partial ] && export DGP_BENCH_PATH=partial || unset DGP_BENCH_PATH
-    timeout -k 10 200 python bench.py --N $n --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('N', $n, '$mode', round(d['ms_per_step_median'],2), {k:round(v,2) for k,v in d['breakdown_ms_per_step'].items()})" || exit 1
+    timeout -k 10 200 python bench.py --N $n --steps 30 --warmup 5 --no-cpu-baseline --nat-steps 0 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('N', $n, '$mode', round(d['ms_per_step_median'],2), {k:round(v,2) for k,v in d['breakdown_ms_per_step'].items()})" || exit 1
   done
 done
