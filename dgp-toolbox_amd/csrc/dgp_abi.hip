@@ -1424,6 +1424,36 @@ int dgp_dev_rbf_contract(dgp_ctx* ctx, const double* G, const double* Z1, const 
   return DGP_OK;
 }
 
+int dgp_dev_g_panel(dgp_ctx* ctx, const double* Cbar, const double* Linv, const double* E, const double* Z1, const double* X1,
+                    int64_t Pn, int32_t w1, double* R1, double* GX, int32_t* used) {
+  if (!ctx || !Cbar || !Linv || !E || !Z1 || !X1 || !R1 || !GX || Pn <= 0 || w1 < 2 || w1 > 9)
+    return fail(ctx, DGP_ERR_INVALID, "dgp_dev_g_panel: bad arguments (Mp = 256, 2 <= w1 <= 9)");
+  HIPCHK(hipSetDevice(ctx->device));
+  const long P = Pn, Mp = 256;
+  const bool ok = g_panel_ok((int)Mp, w1, P);
+  if (used) *used = ok ? 1 : 0;
+  if (!ok) return DGP_OK;                       // (the backward pass would take the stored-g path: dgp_dev_layer_products + dgp_dev_rbf_contract)
+  double *dC = nullptr, *dL = nullptr, *dE = nullptr, *dZ = nullptr, *dX = nullptr, *dR = nullptr, *dGX = nullptr;
+  struct Free { double** p[7]; ~Free() { for (auto q : p) dev_free(*q); } } freer{{&dC, &dL, &dE, &dZ, &dX, &dR, &dGX}};
+  // exactly P rows: the kernel must not touch anything behind them (rows of the last panel past P read as zeros)
+  RET(dev_alloc(ctx, &dC, (size_t)P * Mp)); RET(dev_alloc(ctx, &dL, (size_t)Mp * Mp)); RET(dev_alloc(ctx, &dE, (size_t)P * Mp));
+  RET(dev_alloc(ctx, &dZ, (size_t)Mp * w1)); RET(dev_alloc(ctx, &dX, (size_t)P * w1)); RET(dev_alloc(ctx, &dR, (size_t)P * w1));
+  RET(dev_alloc(ctx, &dGX, (size_t)Mp * w1));
+  HIPCHK(hipMemcpyAsync(dC, Cbar, (size_t)P * Mp * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(dL, Linv, (size_t)Mp * Mp * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(dE, E, (size_t)P * Mp * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(dZ, Z1, (size_t)Mp * w1 * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(dX, X1, (size_t)P * w1 * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(dGX, GX, (size_t)Mp * w1 * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemsetAsync(dR, 0xff, (size_t)P * w1 * 8, ctx->st));
+  if (!ctx->rg_ws) RET(dev_alloc(ctx, &ctx->rg_ws, (size_t)rbf_bwd_contract_ws_doubles()));
+  HIPCHK(g_panel(ctx->st, dC, dL, dE, P, dZ, dX, w1, dR, dGX, ctx->rg_ws, ctx->cu_count, ctx->reserved_cus));      // the call backward_chunk makes
+  HIPCHK(hipMemcpyAsync(R1, dR, (size_t)P * w1 * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipMemcpyAsync(GX, dGX, (size_t)Mp * w1 * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  return DGP_OK;
+}
+
 int dgp_dev_chol(dgp_ctx* ctx, double* A, int32_t M, int32_t batch) {
   if (!ctx || !A || M <= 0 || M % 16 != 0 || batch <= 0) return fail(ctx, DGP_ERR_INVALID, "dgp_dev_chol: M must be a multiple of 16");
   double* d;

@@ -995,7 +995,9 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       ctx->st = ctx->bst;
     }
     struct BackToMain { dgp_ctx* c; hipStream_t m; ~BackToMain() { c->st = m; } } back_to_main{ctx, main_st};
-    {
+    // Stationary kernels at Mp = 256: g, g [Z | 1] and g^T [X | 1] in one launch that never stores g (gemm_gpanel.h)
+    const bool gpanel = y.d.kernel_kind != DGP_KERNEL_MF && !ovl && g_panel_ok(Mp, Din + 1, Pl);
+    if (!gpanel) {
       // g = dK .* e (e = -2 dk/dr2; = k for the squared exponential).  dK itself has one more reader, Q = dK^T C =
       // Linv^T (Cbar^T C): that reduction takes Cbar instead (finish_layer applies Linv^T to the summed 256 x 256 result), so
       // the stationary kernels never write dK: 2 GB per 10^6 points.  (The composite kernel differentiates dK directly.)
@@ -1027,7 +1029,14 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
         ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 16);
         HIPCHK(make_x1(ctx->st, Xin, row0, Pl, Din, ctx->X1));
       }
-      RET(launch_rbf_contract(ctx, ctx->Gt, Pl, Pm, Mp, y.Z1, ctx->X1, w1, ctx->R1, o.params ? acc + y.acc_GX : nullptr, nullptr));
+      if (gpanel) {
+        if (o.params && !ctx->rg_ws) RET(dev_alloc(ctx, &ctx->rg_ws, (size_t)rbf_bwd_contract_ws_doubles()));
+        ProfScope ps(ctx, 0, tri1 + (o.params ? 4.0 : 2.0) * Pl * Mp * w1, (double)Pl * Mp * 16);
+        HIPCHK(g_panel(ctx->st, ctx->Cbar, y.Linv, y.Et ? y.Et : y.Kt, Pl, y.Z1, ctx->X1, w1, ctx->R1, o.params ? acc + y.acc_GX : nullptr,
+                       ctx->rg_ws, ctx->cu_count, ctx->reserved_cus));
+      } else {
+        RET(launch_rbf_contract(ctx, ctx->Gt, Pl, Pm, Mp, y.Z1, ctx->X1, w1, ctx->R1, o.params ? acc + y.acc_GX : nullptr, nullptr));
+      }
       ProfScope ps(ctx, 1, 0, (double)Pl * w1 * 24);
       HIPCHK(xbar_finish(ctx->st, ctx->R1, ctx->X1, Pl, P(ctx, y.off_ls), Din, D, y.d.mean_kind, y.meanW, y.mbar,
                          (l > 0 || o.xgrad0) ? 1 : 0, ctx->xbar, o.params ? acc + y.acc_x2 : nullptr));

@@ -118,6 +118,11 @@ hipError_t sub_scalars(hipStream_t st, const double* a, const double* b, double*
 hipError_t qprime_from_sums(hipStream_t st, const double* T, const double* G, const double* u, const double* du, int Mp, int D, double* Q);
 hipError_t sum_dprod(hipStream_t st, const double* T, const double* a, const double* b, int Mp, int D, double* out);   // out = a b^T + sum_d T[d] (optim.hip)
 hipError_t zero_two(hipStream_t st, double* a, long na, double* b, long nb);                 // both ranges zeroed in one launch (optim.hip)
+hipError_t rg_reduce(hipStream_t st, const double* slab, int nslab, int n, double* GX);       // GX[i] += sum of the slabs, in slab order (points.hip)
+// gemm_gpanel.hip: R1 = g [Z | 1], GX += g^T [X | 1] for g = (Cbar Linv) .* E without storing g (Mp = 256, stationary kernels)
+bool g_panel_ok(int Mp, int w1, long P);
+hipError_t g_panel(hipStream_t st, const double* Cbar, const double* Linv, const double* E, long P, const double* Z1,
+                   const double* X1, int w1, double* R1, double* GX, double* ws, int cu_count, int reserve_cus);
 hipError_t acc_xfer(hipStream_t st, const long* tab, int nseg, double* square, double* packed, bool unpack);   // optim.hip: pack / unpack the transport form of the partial sums
 hipError_t finish_tail_launch(hipStream_t st, const double* acc, double* scal, double* grad_last);   // grad_last = acc[1]; scal[1] = acc[0] - scal[0]
 hipError_t store_q(hipStream_t st, const double* Lq, const double* qmu_p, int M, int Mp, int D, double* q_sqrt,

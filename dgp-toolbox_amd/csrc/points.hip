@@ -729,6 +729,11 @@ __global__ __launch_bounds__(256) void rg_reduce_kernel(const double* __restrict
   for (; b < nslab; ++b) s0 += slab[(long)b * n + i];
   GX[i] += (s0 + s1) + (s2 + s3);
 }
+// (also the reduction of gemm_gpanel.h's slabs)
+hipError_t rg_reduce(hipStream_t st, const double* slab, int nslab, int n, double* GX) {
+  hipLaunchKernelGGL(rg_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nslab, n, GX);
+  LAUNCH_CHECK();
+}
 constexpr int RG_MAX_WG = 512;      // two workgroups per CU (65 KB of LDS each)
 long rbf_bwd_contract_ws_doubles() { return (long)RG_MAX_WG * 256 * 9; }
 bool rbf_bwd_contract_ok(int Mp, int w1, long P) {

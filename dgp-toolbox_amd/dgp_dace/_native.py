@@ -25,7 +25,7 @@ SYMBOLS = [
     "dgp_grad_partial", "dgp_acc_info", "dgp_acc_bind", "dgp_grad_finish", "dgp_grad_get", "dgp_last_elbo", "dgp_grad_step",
     "dgp_comm_available", "dgp_comm_unique_id", "dgp_comm_init", "dgp_comm_destroy", "dgp_comm_allreduce",
     "dgp_adam_reset", "dgp_adam_step", "dgp_adam_iterations", "dgp_natgrad_step", "dgp_prof_enable", "dgp_prof_read", "dgp_prof_mark", "dgp_prof_marks_read", "dgp_dev_gemm", "dgp_dev_gram",
-    "dgp_dev_layer_products", "dgp_dev_rbf_contract",
+    "dgp_dev_layer_products", "dgp_dev_rbf_contract", "dgp_dev_g_panel",
     "dgp_dev_chol", "dgp_dev_trinv", "dgp_dev_normals", "dgp_dev_mfma_peak",
 ]
 
@@ -167,6 +167,7 @@ def load():
         "dgp_dev_gram": (C.c_int, [vp, _dp, _dp, i64, i32, _dp, _dp, _dp]),
         "dgp_dev_layer_products": (C.c_int, [vp, i64, i32, i32] + [_dp] * 15 + [C.POINTER(i32)]),
         "dgp_dev_rbf_contract": (C.c_int, [vp, _dp, _dp, _dp, i64, i32, i32, _dp, _dp, C.POINTER(i32)]),
+        "dgp_dev_g_panel": (C.c_int, [vp, _dp, _dp, _dp, _dp, _dp, i64, i32, _dp, _dp, C.POINTER(i32)]),
         "dgp_dev_chol": (C.c_int, [vp, _dp, i32, i32]),
         "dgp_dev_trinv": (C.c_int, [vp, _dp, _dp, i32, i32]),
         "dgp_dev_normals": (C.c_int, [vp, u64, i32, i32, i64, i64, i32, _dp]),
@@ -554,6 +555,18 @@ class Context:
         f = C.c_int32(0)
         self._chk(self._lib.dgp_dev_rbf_contract(self._h, _ptr(G), _ptr(Z1), _ptr(X1), P, Mp, w1, _ptr(R1), _ptr(GX), C.byref(f)))
         return R1, GX, bool(f.value)
+
+    def dev_g_panel(self, Cbar, Linv, E, Z1, X1, GX0=None):
+        """R1 = g Z1 and GX (+)= g^T X1 for g = (Cbar Linv) .* E through the launch the backward pass uses at Mp = 256
+        (dgp_dev_g_panel; g is never stored).  Returns (R1, GX, used); used False: the size goes down the stored-g path."""
+        Cbar, Linv, E, Z1, X1 = _c(Cbar), _c(Linv), _c(E), _c(Z1), _c(X1)
+        P, w1 = Cbar.shape[0], Z1.shape[1]
+        assert Cbar.shape == (P, 256) and E.shape == (P, 256) and Linv.shape == (256, 256) and Z1.shape == (256, w1) and X1.shape == (P, w1)
+        R1 = np.empty((P, w1))
+        GX = np.zeros((256, w1)) if GX0 is None else _c(GX0).copy()
+        u = C.c_int32(0)
+        self._chk(self._lib.dgp_dev_g_panel(self._h, _ptr(Cbar), _ptr(Linv), _ptr(E), _ptr(Z1), _ptr(X1), P, w1, _ptr(R1), _ptr(GX), C.byref(u)))
+        return R1, GX, bool(u.value)
 
     def dev_chol(self, A):
         A = _c(A).copy()

@@ -261,6 +261,12 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t P, int32_t Mp, int32_t D, const
  * as two products on the 128 x 64 engine. */
 int dgp_dev_rbf_contract(dgp_ctx* ctx, const double* G, const double* Z1, const double* X1, int64_t P, int32_t Mp, int32_t w1,
                          double* R1, double* GX /* in/out */, int32_t* fused);
+/* The same backward step in the form training uses from round 4 on for stationary kernels with 256 (padded) inducing points:
+ * g = (Cbar Linv) .* E is never stored; one launch (csrc/gemm_gpanel.h) returns R1 [P, w1] = g Z1 and GX [256, w1] += g^T X1
+ * (Cbar, E [P, 256]; Linv [256, 256] lower triangular; 2 <= w1 <= 9).  *used: 1 when that kernel ran, 0 when the size / switches
+ * send the backward pass down the stored-g path instead (then nothing is computed here). */
+int dgp_dev_g_panel(dgp_ctx* ctx, const double* Cbar, const double* Linv, const double* E, const double* Z1, const double* X1,
+                    int64_t P, int32_t w1, double* R1, double* GX /* in/out */, int32_t* used);
 int dgp_dev_chol(dgp_ctx* ctx, double* A, int32_t M, int32_t batch);            /* in place, lower */
 int dgp_dev_trinv(dgp_ctx* ctx, const double* L, double* X, int32_t M, int32_t batch);
 int dgp_dev_normals(dgp_ctx* ctx, uint64_t seed, int32_t layer, int32_t S, int64_t n0, int64_t N, int32_t D,

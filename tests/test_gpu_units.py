@@ -316,3 +316,35 @@ def test_one_rocm_stack_in_the_normal_load_order(ctx):
     paths = _native.check_one_hip_runtime()
     assert len(paths) == 1, paths
     assert paths == _native.hip_runtimes_in(open("/proc/self/maps"))
+
+
+@pytest.mark.parametrize("P,w1", [(49280, 9), (12496, 9), (100001, 9), (4224, 2), (20000, 5)])
+def test_g_panel_kernel_every_element_against_numpy(ctx, P, w1):
+    """csrc/gemm_gpanel.h, the launch that replaces `g = (Cbar Linv) .* k`, `g [Z | 1]` and `g^T [X | 1]` of the backward pass
+    through Kuf (what tf.GradientTape derives for layers.py:243 under dgp.py:272-275) at 256 inducing
+    points: every element of R1 and GX against NumPy.  Sizes: several panels per workgroup; a rank's share of 8 GPUs (98 panels
+    for 256 workgroups); a ragged last panel (rows past P must read as zeros, R1 must not be written behind P); the smallest
+    and a middle input width."""
+    rng = np.random.default_rng(P + w1)
+    Cbar = rng.standard_normal((P, 256))
+    E = rng.uniform(0.1, 1.0, (P, 256))
+    Linv = np.tril(rng.standard_normal((256, 256))) / 16.0
+    Z1 = rng.standard_normal((256, w1))
+    X1 = rng.standard_normal((P, w1))
+    GX0 = rng.standard_normal((256, w1))
+    R1, GX, used = ctx.dev_g_panel(Cbar, Linv, E, Z1, X1, GX0)
+    assert used
+    g = (Cbar @ Linv) * E
+    R1_ref, GX_ref = g @ Z1, GX0 + g.T @ X1
+    assert np.abs(R1 - R1_ref).max() < 1e-12 * np.abs(R1_ref).max()
+    assert np.abs(GX - GX_ref).max() < 1e-12 * np.abs(GX_ref).max()
+    # reproducible: no atomics anywhere in the launch
+    R1b, GXb, _ = ctx.dev_g_panel(Cbar, Linv, E, Z1, X1, GX0)
+    assert np.array_equal(R1, R1b) and np.array_equal(GX, GXb)
+
+
+def test_g_panel_declines_small_inputs(ctx):
+    rng = np.random.default_rng(0)
+    P = 1000
+    _, _, used = ctx.dev_g_panel(rng.standard_normal((P, 256)), np.eye(256), np.ones((P, 256)), np.ones((256, 3)), np.ones((P, 3)))
+    assert not used

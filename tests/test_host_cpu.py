@@ -108,8 +108,8 @@ def test_library_exports_every_symbol_declared_in_the_header():
     header = open(os.path.join(ROOT, "include", "dgp_abi.h")).read()
     declared = sorted(set(re.findall(r"^(?:int|void|int64_t|const char\*)\s+(dgp_[a-z_0-9]+)\s*\(", header, re.M)))
     assert declared == sorted(_native.SYMBOLS)
-    lib = ctypes.CDLL(_native.LIB_PATH)
-    for s in declared:
+    lib = _native.load()          # (torch first, then the library: a bare CDLL here would bring the system ROCm stack in
+    for s in declared:            #  ahead of torch's - exactly what test_two_rocm_stacks_in_one_process_are_detected refuses)
         assert hasattr(lib, s), s
 
 
