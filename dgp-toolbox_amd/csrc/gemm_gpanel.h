@@ -168,8 +168,6 @@ void g_panel_kernel(GPanelArgs g) {
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (n + 2 <= 15) { issue_B(t - 2, (n + 2) % 3); load_A(cur, t - 2, (n + 2) % 3); }
-      __builtin_amdgcn_sched_barrier(0);
       // units (k-step, block): B fragment two units ahead
       constexpr int NB = t + 1, U = 4 * NB;
       double fb[3][4];
@@ -184,6 +182,10 @@ void g_panel_kernel(GPanelArgs g) {
       if constexpr (U > 1) readB(1, 1);
       w_static_for<0, U>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value, ks = u / NB, j = u % NB, s8 = ks >> 1, q = ks & 1;
+        // the requests for tile n + 2 go out a few units into the tile (its stage was released by the barrier above): issued
+        // right behind the barrier, all eight waves spent their first ~500 cycles of every k-tile on them with the matrix
+        // cores idle
+        if constexpr (u == (U > 3 ? 3 : U - 1) && n + 2 <= 15) { issue_B(t - 2, (n + 2) % 3); load_A(cur, t - 2, (n + 2) % 3); }
         if constexpr (u + 2 < U) readB((u + 2) % 3, u + 2);
         const double a = fa[st][s8][q];
         // (tied accumulators: with the builtin hipcc renames the 64 accumulator pairs and spills ~200 registers; as in
@@ -207,24 +209,27 @@ void g_panel_kernel(GPanelArgs g) {
       issue_B(15, 0); load_A(cur, 15, 0);
       issue_B(14, 1); load_A(cur, 14, 1);
     }
-    // factor E of the round's 16 x 256 image: thread -> row tid / 32, eight columns from 8 (tid % 32), one round ahead
-    const int erow = tid >> 5, ecol = (tid & 31) * 8;
+    // factor E of the round's 16 x 256 image, one round ahead: thread -> row tid / 32, the 16-byte chunks tid % 32 + 32 q4 of the
+    // row (consecutive lanes on consecutive chunks: coalesced loads, conflict-free LDS accesses; eight consecutive columns per
+    // thread put the lanes 64 bytes apart - four-way bank conflicts on every access of the multiply)
+    const int erow = tid >> 5, ecol = (tid & 31) * 2;
     d2_t er[4];
     auto load_Er = [&](long row0) __attribute__((always_inline)) {
       if (row0 + erow < g.P) {
         const d2_t* src = reinterpret_cast<const d2_t*>(g.E + (row0 + erow) * 256 + ecol);
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) er[q4] = src[q4];
+        for (int q4 = 0; q4 < 4; ++q4) er[q4] = src[32 * q4];
       } else {
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) er[q4] = (d2_t){0.0, 0.0};
       }
     };
     load_Er(prow0);
+    // (the round's rows of X1 are fetched one round ahead as well: fetched at the top of their own round they were waited for
+    //  in front of the round's second barrier - about a memory latency per round, eight times per panel)
+    double xv = (tid < 16 * W && prow0 + xp < g.P) ? g.X1[(prow0 + xp) * W + xj] : 0.0;
     for (int r = 0; r < 8; ++r) {
       const long rrow0 = prow0 + 16 * r;
-      double xv = 0.0;
-      if (tid < 16 * W && rrow0 + xp < g.P) xv = g.X1[(rrow0 + xp) * W + xj];
       __syncthreads();            // the previous round's reads of sG / sX are done, its partials are complete in sP[(r - 1) & 1]
       if (r > 0 && tid < 16 * W && rrow0 - 16 + xp < g.P) {
         const double* p = sP + ((r - 1) & 1) * (8 * 64 * 3) + r1_lane * 3 + r1_e;
@@ -238,12 +243,15 @@ void g_panel_kernel(GPanelArgs g) {
           *reinterpret_cast<d2_t*>(row + 16 * j + 2) = (d2_t){acc[j][2], acc[j][3]};
         }
       }
-      if (tid < 16 * W) sX[xp * 12 + xjj] = xv;
+      if (tid < 16 * W) {
+        sX[xp * 12 + xjj] = xv;
+        xv = (r + 1 < 8 && rrow0 + 16 + xp < g.P) ? g.X1[(rrow0 + 16 + xp) * W + xj] : 0.0;
+      }
       __syncthreads();
       {                           // g = dK .* E in place, then the next round's factor
         d2_t* im = reinterpret_cast<d2_t*>(sG + erow * GP_PITCH + ecol);
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) im[q4] = im[q4] * er[q4];
+        for (int q4 = 0; q4 < 4; ++q4) im[32 * q4] = im[32 * q4] * er[q4];
         if (r + 1 < 8) load_Er(rrow0 + 16);
       }
       __syncthreads();

@@ -7,7 +7,7 @@
 //         dgp-toolbox_amd/csrc/gemm_f64.hip dgp-toolbox_amd/csrc/gemm_wide.hip dgp-toolbox_amd/csrc/gemm_gram.hip \
 //         dgp-toolbox_amd/csrc/gemm_tall.hip dgp-toolbox_amd/csrc/gemm_tallu.hip dgp-toolbox_amd/csrc/gemm_small.hip \
 //         dgp-toolbox_amd/csrc/gemm_mid.hip -o tools/tall_bench
-//   tools/tall_bench [rows] [reps] [D] [which: bitmask 1 T/NT, 2 T/plain, 4 T/no store, 8 dC, 16 Gram]
+//   tools/tall_bench [rows] [reps] [D] [which: bitmask 1 T/NT, 2 T/plain, 4 T/no store, 8 dC, 16 Gram, 32 g row-panel]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +17,7 @@
 #include <functional>
 #include "gemm_tall.h"
 #include "gemm_tallu.h"
+#include "dgp_internal.h"
 using namespace dgp;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -109,6 +110,18 @@ int main(int argc, char** argv) {
       const float t = time_ms(st, reps, [&]() { CK(gemm_f64(st, GEMM_TN, a)); });
       printf("G_d = sum_p v_pd c_p c_pT (Gram kernel)   %8.3f ms  %5.1f TFLOP/s algorithmic\n", t, flopsT / t / 1e9);
     }
+  }
+  if (which & 32) {
+    double* Z1 = dalloc(256 * 9); fill_rand(Z1, 256 * 9, 8);
+    double* X1 = dalloc((size_t)P * 9); fill_rand(X1, (size_t)P * 9, 9);
+    double* R1 = dalloc((size_t)P * 9);
+    double* GXa = dalloc(256 * 9); CK(hipMemset(GXa, 0, 256 * 9 * 8));
+    double* gws = dalloc(512L * 256 * 9);
+    double* Lv = dalloc(65536); fill_tri_blocks(Lv, 256, 256, true, 10);
+    const float t = time_ms(st, reps, [&]() { CK(g_panel(st, Ct, Lv, T, P, Z1, X1, 9, R1, GXa, gws, cus, 0)); });
+    const double fl = (double)P * 256.0 * 257.0 + 4.0 * P * 256.0 * 9.0;
+    printf("R1, GX of g = (dC Linv) .* k (row-panel kernel) %8.3f ms  %5.1f TFLOP/s algorithmic; inputs %.2f GB -> %.2f TB/s\n", t, fl / t / 1e9,
+           2.0 * P * 2048 / 1e9, 2.0 * P * 2048 / t / 1e9);
   }
   CK(hipDeviceSynchronize());
   return 0;
