@@ -245,7 +245,7 @@ def main():
         # HBM bytes per launch of the dominant kernel family: NOT measured in this run (PMC counters need rocprofv3 passes
         # of their own); taken from the committed summary of those passes, whose commit / command travel with the number
         traffic, traffic_source = None, None
-        tpath = os.environ.get("DGP_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
+        tpath = os.environ.get("DGP_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")
         if world == 1 and os.path.exists(tpath) and (args.N, args.M, args.S) == (100_000, 256, 10):
             try:
                 tj = json.load(open(tpath))
@@ -269,7 +269,7 @@ def main():
                                         "one all-reduce of the partial-sum buffer per iteration (process group's collective) before the replicated small-matrix chains and Adam"))},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_tallu_kernel + dgp::gemm_gram_kernel + dgp::gemm_f64_kernel (all point contractions, rank 0)",
+                         "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_tallu_kernel + dgp::gemm_gram_kernel + dgp::g_panel_kernel + dgp::gemm_f64_kernel (all point contractions, rank 0)",
                          "kernel_ms_per_step": mf["ms"] / args.steps, "launches_per_step": mf["launches"] / args.steps,
                          "alg_flops_per_step_rank0": mf["alg_flops"] / args.steps,
                          "whole_step_frac": alg_flops_step(args.minibatch or args.N, args.S, dims, args.M, 1) / world / (dt / args.steps)

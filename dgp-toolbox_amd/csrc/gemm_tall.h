@@ -169,7 +169,13 @@ void gemm_tall_kernel(TallArgs g) {
   double rsum[2] = {0.0, 0.0};
   unsigned vo[2];
 #pragma unroll
+#ifdef TL_STORE_SECTOR
+  // (timing experiment only - the layout the consumers read is the other one: a lane's two 16-byte stores 64 bytes apart, so
+  //  that ONE store instruction fills whole 32-byte sectors: [c0 e01][c1 e01][c2 e01][c3 e01] | [c0 e23] ...)
+  for (int i = 0; i < 2; ++i) vo[i] = (unsigned)((((wave & 3) * 32 + i * 16 + 4 * (li >> 2) + lk) * 16 + 2 * (li & 3)) * 8);
+#else
   for (int i = 0; i < 2; ++i) vo[i] = (unsigned)((((wave & 3) * 32 + i * 16 + 4 * (li >> 2) + lk) * 16 + 4 * (li & 3)) * 8);
+#endif
   typedef unsigned u4_t __attribute__((ext_vector_type(4)));
   typedef unsigned u2_t __attribute__((ext_vector_type(2)));
   auto flush = [&](auto jc, unsigned tm, unsigned d, int h, bool last_block) __attribute__((always_inline)) {
@@ -208,7 +214,11 @@ void gemm_tall_kernel(TallArgs g) {
       for (int i = 0; i < 2; ++i) {
         const d2_t v0 = {acc[i][j][0], acc[i][j][1]}, v1 = {acc[i][j][2], acc[i][j][3]};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v0), rc, vo[i], 0, NT ? 2 : 0);
+#ifdef TL_STORE_SECTOR
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v1), rc, vo[i] + 64, 0, NT ? 2 : 0);
+#else
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v1), rc, vo[i] + 16, 0, NT ? 2 : 0);
+#endif
       }
     }
     // The accumulators of the column restart from zero.  Written HERE by explicit moves: the MFMAs are inline asm (hipcc
