@@ -1335,13 +1335,13 @@ int dgp_dev_layer_products(dgp_ctx* ctx, int64_t Pn, int32_t Mp, int32_t D, cons
   const bool with_alpha = Mp == 256 && D <= 8;          // as dgp_set_layers allocates it
   if (with_alpha) RET(G(ctx, 2, GEMM_NN, Mp, D, Mp, dLinvT, Mp, du_, D, dal, D, 1.0, 0));      // alpha = LinvT u, as prep() does
   GemmArgs aC = args_Ct(Pm, Mp, dKt, dLinvT, dCt, cnp, with_alpha ? dal : nullptr, dm0, D);
-  GemmArgs aT = args_T(Pm, Mp, D, dCt, dW, dT, tnp, ctx->blocked_t);
+  GemmArgs aT = args_T(Pm, Mp, D, dCt, dW, dT, tnp, t_blocked(ctx, Pm, Mp, D));
   int nplane = 0, nplane_t = 0;
   bool mean_done = false;
   RET(launch_Ct_T(ctx, aC, aT, dLinv, P, &nplane, &nplane_t, &mean_done));
   if (!mean_done) RET(GX(ctx, 0, GEMM_NN, args_mean0(Pm, Mp, D, dCt, du_, dm0)));
   // backward (backward_chunk, stored-T form)
-  GemmArgs aB = args_Cbar(Pm, Mp, D, dT, dS, dCb, dvb, dCt, dmb, du_, ctx->blocked_t);
+  GemmArgs aB = args_Cbar(Pm, Mp, D, dT, dS, dCb, dvb, dCt, dmb, du_, t_blocked(ctx, Pm, Mp, D));
   RET(GX(ctx, 0, GEMM_NN, aB));
   GemmArgs aG = args_g(Pm, Mp, dCb, dLinv, dKb, dKt, dG);
   RET(GX(ctx, 0, GEMM_NN, aG));

@@ -764,7 +764,10 @@ GemmArgs args_Ct(long Pm, int Mp, const double* Kt, const double* LinvT, double*
   if (alpha && mean0 && D >= 1 && D <= 8) { a.mean_alpha = alpha; a.mean_out = mean0; a.mean_d = D; }
   return a;
 }
-// t_d = W_d^T c: T = Ct * Wcat (W_d lower), row sums |t_d|^2 into planes; T itself (blocked layout) only when Tt != nullptr
+// T is stored in the engine's blocked layout, unless the dC product of this shape runs on the row-panel kernel
+// (gemm_dcpanel.h), which reads a plain row-major T
+bool t_blocked(const dgp_ctx* ctx, long Pm, int Mp, int D) { return ctx->blocked_t && !dc_panel_shape_ok(Pm, Mp, D); }
+// t_d = W_d^T c: T = Ct * Wcat (W_d lower), row sums |t_d|^2 into planes; T itself (blocked or row-major) only when Tt != nullptr
 GemmArgs args_T(long Pm, int Mp, int D, const double* Ct, const double* Wcat, double* Tt, double* tnp, bool blocked) {
   GemmArgs a = mk(Pm, (long)D * Mp, Mp, Ct, Mp, Wcat, (long)D * Mp, Tt, (long)D * Mp);
   a.tri = TRI_B_LOWER; a.triblk = Mp; a.epi = Tt ? 2 : 1; a.rowsq = tnp; a.rowsq_ld = Pm;
@@ -876,7 +879,7 @@ int forward_chunk(dgp_ctx* ctx, const double* Xsrc, long Ntot, long n0, long Nc,
     // the backward pass, store_t).  Both run on the wide-tile kernel (gemm_wide.h: 2 partial planes per 256 columns)
     // when it applies, else on the 128 x 64 engine (Mp/32 planes, the triangular solve as an NT product).
     GemmArgs aC = args_Ct(Pm, Mp, y.Kt, y.LinvT, y.Ct, y.cnp, y.alpha, y.mean0, D);
-    GemmArgs aT = args_T(Pm, Mp, D, y.Ct, y.Wcat, y.Tt, y.tnp, ctx->blocked_t);
+    GemmArgs aT = args_T(Pm, Mp, D, y.Ct, y.Wcat, y.Tt, y.tnp, t_blocked(ctx, Pm, Mp, D));
     int nplane = 0, nplane_t = 0;
     if (small_fused(ctx, y)) {
       // at most 64 inducing points: Kuf, c, t_d, mean0 and the row norms in ONE launch (small_layer.hip)
@@ -969,7 +972,7 @@ int backward_chunk(dgp_ctx* ctx, long n0, long Nc, int S, uint64_t seed, bool us
       continue;
     }
     if (y.Tt) {  // dC = sum_d 2 vbar_d (W_d t_d - c): [2 vbar .* T] * WTcat, W_d lower => k <= n per block; "- c" in the epilogue
-      GemmArgs a = args_Cbar(Pm, Mp, D, y.Tt, y.Scat, ctx->Cbar, y.vbar, y.Ct, y.mbar, y.u, ctx->blocked_t);
+      GemmArgs a = args_Cbar(Pm, Mp, D, y.Tt, y.Scat, ctx->Cbar, y.vbar, y.Ct, y.mbar, y.u, t_blocked(ctx, Pm, Mp, D));
       RET(GX(ctx, 0, GEMM_NN, a, tri1 * D, (double)Pl * Mp * 8 * (2 + D)));
     } else {  // dC = sum_d 2 vbar_d .* (C S'_d)      (A operand scaled on the fly; K = D*Mp re-reads C per block)
       GemmArgs a = mk(Pm, Mp, DM, y.Ct, Mp, y.Scat, Mp, ctx->Cbar, Mp, 2.0, 0);

@@ -754,6 +754,10 @@ hipError_t gemm_tall(hipStream_t st, const GemmArgs& a);
 // tall-tile kernel for the backward dC product (gemm_tallu.h / gemm_tallu.hip)
 bool gemm_tallu_ok(const GemmArgs& a);
 hipError_t gemm_tallu(hipStream_t st, const GemmArgs& a);
+// gemm_dcpanel.h / .hip: the same product from a row-major T (128-row panels, T read once)
+bool dc_panel_shape_ok(long M, long Mp, long D);     // would the dC product of this shape run there?  (then T is written row-major)
+bool dc_panel_ok(const GemmArgs& a);
+hipError_t dc_panel(hipStream_t st, const GemmArgs& a);
 // weighted Gram products over the points (gemm_gram.h / gemm_gram.hip)
 // latency-oriented products of the chains' Mp x Mp matrices (gemm_mid.hip)
 bool gemm_mid_ok(GemmOp op, const GemmArgs& a);

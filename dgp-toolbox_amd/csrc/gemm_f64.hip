@@ -186,7 +186,8 @@ int gemm_engine_of(GemmOp op, const GemmArgs& args) {
   if (gemm_mid_ok(op, a)) return 6;        // the chains' Mp x Mp products (K <= 256, few engine tiles): 32 x 32 tiles, k range staged once
   // row-panel products with a (block-)triangular or dense Mp-wide B: the tall-tile kernels, else the wide-tile kernel
   if (op == GEMM_NN && !a.no_wide && gemm_tall_ok(a)) return 2;      // T = Ct * Wcat at Mp = 256: 256 x 128 tiles
-  if (op == GEMM_NN && !a.no_wide && gemm_tallu_ok(a)) return 3;     // dC = [2 vbar .* T] * W^T ... at Mp = 256, likewise
+  if (op == GEMM_NN && !a.no_wide && dc_panel_ok(a)) return 7;       // dC from a ROW-MAJOR T at Mp = 256: 128-row panels, A straight into registers (gemm_dcpanel.h)
+  if (op == GEMM_NN && !a.no_wide && gemm_tallu_ok(a)) return 3;     // dC = [2 vbar .* T] * W^T ... at Mp = 256 from the blocked T, 256 x 128 tiles
   if (op == GEMM_NN && !a.no_wide && gemm_wide_ok(a)) return 1;
   // weighted Gram products over the points (lower triangle, Mp = 256): the single-staging kernel of gemm_gram.h
   if (op == GEMM_TN && !a.no_wide && gemm_gram_ok(a)) return 4;
@@ -207,6 +208,7 @@ hipError_t gemm_f64(hipStream_t st, GemmOp op, const GemmArgs& args) {
     case 6: return gemm_mid(st, op, a);
     case 2: return gemm_tall(st, a);
     case 3: return gemm_tallu(st, a);
+    case 7: return dc_panel(st, a);
     case 1: return gemm_wide(st, a);
     case 4: return gemm_gram(st, a);
     default: break;

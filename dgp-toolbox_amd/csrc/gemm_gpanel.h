@@ -228,7 +228,11 @@ void g_panel_kernel(GPanelArgs g) {
     // (the round's rows of X1 are fetched one round ahead as well: fetched at the top of their own round they were waited for
     //  in front of the round's second barrier - about a memory latency per round, eight times per panel)
     double xv = (tid < 16 * W && prow0 + xp < g.P) ? g.X1[(prow0 + xp) * W + xj] : 0.0;
+#ifdef GP_DBG_NO_ROUNDS      // (timing experiment: the k-tiles alone)
+    for (int r = 0; r < 0; ++r) {
+#else
     for (int r = 0; r < 8; ++r) {
+#endif
       const long rrow0 = prow0 + 16 * r;
       __syncthreads();            // the previous round's reads of sG / sX are done, its partials are complete in sP[(r - 1) & 1]
       if (r > 0 && tid < 16 * W && rrow0 - 16 + xp < g.P) {

@@ -33,6 +33,7 @@ struct TallArgs {
   double* rowsq; long rowsq_ld;  // planes [2 D][rowsq_ld]: plane 2 d + h = sum of squares over columns 128 h .. 128 h + 127 of block d
   long M;                        // rows, a multiple of 128 (the last tile may be half empty)
   int D;
+  int rowmajor;                  // T as a plain [M][ldc] array (read back by gemm_dcpanel.h) instead of the blocked layout
 };
 
 // position p = 0..23 inside a (row tile, d) pair: p < 16: left half (h = 0), k-tile t = p, blocks 0..min(p, 7);
@@ -168,14 +169,19 @@ void gemm_tall_kernel(TallArgs g) {
   //      T[256 tm + 32 w + 16 i + 4 (li >> 2) + lk][256 d + 128 h + 16 j + 4 (li & 3) + e]
   double rsum[2] = {0.0, 0.0};
   unsigned vo[2];
+  if (g.rowmajor) {
 #pragma unroll
+    for (int i = 0; i < 2; ++i) vo[i] = (unsigned)(((long)(i * 16 + 4 * (li >> 2) + lk) * g.ldc + 4 * (li & 3)) * 8);
+  } else {
 #ifdef TL_STORE_SECTOR
   // (timing experiment only - the layout the consumers read is the other one: a lane's two 16-byte stores 64 bytes apart, so
   //  that ONE store instruction fills whole 32-byte sectors: [c0 e01][c1 e01][c2 e01][c3 e01] | [c0 e23] ...)
   for (int i = 0; i < 2; ++i) vo[i] = (unsigned)((((wave & 3) * 32 + i * 16 + 4 * (li >> 2) + lk) * 16 + 2 * (li & 3)) * 8);
 #else
+#pragma unroll
   for (int i = 0; i < 2; ++i) vo[i] = (unsigned)((((wave & 3) * 32 + i * 16 + 4 * (li >> 2) + lk) * 16 + 4 * (li & 3)) * 8);
 #endif
+  }
   typedef unsigned u4_t __attribute__((ext_vector_type(4)));
   typedef unsigned u2_t __attribute__((ext_vector_type(2)));
   auto flush = [&](auto jc, unsigned tm, unsigned d, int h, bool last_block) __attribute__((always_inline)) {
@@ -208,7 +214,8 @@ void gemm_tall_kernel(TallArgs g) {
       // resource base, the instruction's scalar offset stays 0 (gemm_wide.h: store / data-register hazard).  The
       // stores are ALWAYS issued (the vmcnt bookkeeping is compile-time): a wave whose rows lie past M gets a resource of
       // zero records, which drops them
-      const double* cb = g.C + ((long)tm * 2 + (wave >> 2)) * 128 * g.ldc + ((long)d * 16 + 8 * h + j) * 2048;
+      const double* cb = g.rowmajor ? g.C + ((long)tm * 256 + wave * 32) * g.ldc + (long)d * 256 + 128 * h + 16 * j
+                                    : g.C + ((long)tm * 2 + (wave >> 2)) * 128 * g.ldc + ((long)d * 16 + 8 * h + j) * 2048;
       const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(cb), 0, nrec, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {

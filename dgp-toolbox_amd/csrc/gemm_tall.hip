@@ -12,7 +12,7 @@ bool gemm_tall_ok(const GemmArgs& a) {
   if (a.tri != TRI_B_LOWER || a.triblk != 256 || a.K != 256 || a.N % 256 != 0 || a.M % 128 != 0) return false;
   if (a.ldb != a.N || a.lda < 256 || a.alpha != 1.0 || a.beta != 0 || a.batch != 1 || a.splits > 1) return false;
   if (a.rank != 0 || a.eadd != nullptr || a.C2 != nullptr || a.emul != nullptr || a.ascale_mode != 0 || a.a_blocked) return false;
-  if (a.epi == 2) { if (!a.c_blocked || a.C == nullptr || a.ldc != a.N) return false; }
+  if (a.epi == 2) { if (a.C == nullptr || a.ldc != a.N || a.ldc * 8 * 32 >= (1L << 31)) return false; }      // (blocked or row-major T)
   else if (a.epi != 1) return false;
   if (a.rowsq == nullptr) return false;
   if ((reinterpret_cast<uintptr_t>(a.A) & 15u) || (reinterpret_cast<uintptr_t>(a.B) & 15u) || (a.C && (reinterpret_cast<uintptr_t>(a.C) & 15u))) return false;
@@ -30,6 +30,7 @@ hipError_t gemm_tall(hipStream_t st, const GemmArgs& a) {
   g.C = a.epi == 2 ? a.C : nullptr; g.ldc = a.ldc;
   g.rowsq = a.rowsq; g.rowsq_ld = a.rowsq_ld;
   g.M = a.M; g.D = (int)(a.N / 256);
+  g.rowmajor = (a.epi == 2 && !a.c_blocked) ? 1 : 0;
   const long ntile = ((a.M + 255) / 256) * g.D;
   const long gmax = gemm_persistent_grid(a, cus);
   const unsigned grid = (unsigned)(ntile < gmax ? ntile : gmax);

@@ -522,7 +522,7 @@ class Context:
         self._chk(self._lib.dgp_dev_gram(self._h, _ptr(Cmat), _ptr(sp), Cmat.shape[0], D, _ptr(G), _ptr(mbp), _ptr(du)))
         return G, du
 
-    ENGINES = {0: "engine128x64", 1: "wide", 2: "tall", 3: "tallu", 4: "gram", 5: "small", 6: "mid"}
+    ENGINES = {0: "engine128x64", 1: "wide", 2: "tall", 3: "tallu", 4: "gram", 5: "small", 6: "mid", 7: "dcpanel"}
 
     def dev_layer_products(self, Kt, Linv, Wcat, u, vbar, mbar):
         """The point contractions of one SVGP layer (dgp_dev_layer_products) on explicit operands: Kt [P, Mp], Linv [Mp, Mp]

@@ -101,17 +101,20 @@ def test_weighted_gram_kernel_against_numpy(ctx, P, D):
 
 
 # (P, Mp, D, kernel families expected for Ct / T / dC [/ du / G_d]).  The wide-tile kernel takes a row-panel product from 192
-# tiles of 128 x 256 on (csrc/gemm_wide.hip): `Ct` and `dC` (256 columns) from 24 576 rows, `T` from 24 576 / D rows; the tall-tile
-# kernels (Mp = 256) replace its `T` / `dC` modes.  98 432 = 769 x 128 rows: the last 256-row tile is half empty.
+# tiles of 128 x 256 on (csrc/gemm_wide.hip): `Ct` (256 columns) from 24 576 rows, `T` from 24 576 / D rows; the tall-tile kernel
+# (Mp = 256) replaces its `T` mode; `dC` at Mp = 256 runs on the row-panel kernel (csrc/gemm_dcpanel.h, from 4096 rows on) from a
+# ROW-MAJOR T - the tall kernel then writes T row-major.  98 432 = 769 x 128 rows: the last 256-row tile of T is half empty.
 PRODUCTION_CASES = [
-    (98304 + 128, 256, 8, ("wide", "tall", "tallu", "gram", "gram")),        # (du rides on G_d's Gram launch)
-    (98304, 256, 1, ("wide", "tall", "tallu", "gram", "gram")),
-    (98304 + 384, 256, 3, ("wide", "tall", "tallu", "gram", "gram")),
+    (98304 + 128, 256, 8, ("wide", "tall", "dcpanel", "gram", "gram")),        # (du rides on G_d's Gram launch)
+    (98304, 256, 1, ("wide", "tall", "dcpanel", "gram", "gram")),
+    (98304 + 384, 256, 3, ("wide", "tall", "dcpanel", "gram", "gram")),
+    (300032 + 128, 256, 2, ("wide", "tall", "tallu", "gram", "gram")),         # above the row-panel kernel's window: blocked T, gemm_tallu.h
     (49152 + 128, 512, 2, ("wide", "wide", "wide")),          # BASELINE config 4's inducing count
-    (20000, 256, 8, ("engine128x64", "tall", "engine128x64")),   # below the limits of Ct / dC (157 tiles): the 128 x 64 engine, padded rows; T (1256 tiles) is eligible on its own
-    (25008, 256, 8, ("wide", "tall", "tallu", "gram", "gram")),   # one rank's share of 4: the first layer's shape (196 tiles of Ct)
-    (12496, 256, 8, ("engine128x64", "tall", "engine128x64")),   # one rank's share of 8: the first layer's shape
-    (12496, 256, 1, ("engine128x64", "engine128x64", "engine128x64")),
+    (20000, 256, 8, ("engine128x64", "tall", "dcpanel")),     # below the limit of Ct (157 tiles): the 128 x 64 engine, padded rows; T (1256 tiles) is eligible on its own
+    (25008, 256, 8, ("wide", "tall", "dcpanel", "gram", "gram")),   # one rank's share of 4: the first layer's shape (196 tiles of Ct)
+    (12496, 256, 8, ("engine128x64", "tall", "dcpanel")),     # one rank's share of 8: the first layer's shape (98 panels of dC for 256 workgroups)
+    (12496, 256, 1, ("engine128x64", "engine128x64", "dcpanel")),
+    (12496 + 37, 256, 5, ("engine128x64", "tall", "dcpanel")),      # a ragged last panel: rows past P read as zeros and are not stored
     (3001, 192, 2, ("engine128x64", "engine128x64", "engine128x64")),
 ]
 
@@ -132,9 +135,20 @@ def test_layer_products_on_the_wide_tile_kernel_modes_against_numpy():
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     specs = [f"{P}:{Mp}:{D}:wide,wide,wide,gram,gram" for P, Mp, D, e in PRODUCTION_CASES[:3]]
-    env = dict(os.environ, DGP_TALL="0", DGP_TALLU="0")
+    env = dict(os.environ, DGP_TALL="0", DGP_TALLU="0", DGP_DCPANEL="0")
     p = subprocess.run([sys.executable, os.path.join(here, "layer_products_check.py")] + specs, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=1200)
+    assert p.returncode == 0 and p.stdout.count("ok ") == len(specs), p.stdout
+
+
+def test_layer_products_on_the_blocked_t_tall_tile_pair_against_numpy():
+    """With DGP_DCPANEL = 0 the dC product goes back to csrc/gemm_tallu.h and T to the blocked layout that kernel reads: the
+    round-2/3 pair stays correct (it is the fallback when the row-panel kernel is switched off).  Child process."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    specs = [f"{P}:{Mp}:{D}:wide,tall,tallu,gram,gram" for P, Mp, D, e in PRODUCTION_CASES[:3]]
+    p = subprocess.run([sys.executable, os.path.join(here, "layer_products_check.py")] + specs, env=dict(os.environ, DGP_DCPANEL="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
     assert p.returncode == 0 and p.stdout.count("ok ") == len(specs), p.stdout
 
 

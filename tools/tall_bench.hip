@@ -7,7 +7,7 @@
 //         dgp-toolbox_amd/csrc/gemm_f64.hip dgp-toolbox_amd/csrc/gemm_wide.hip dgp-toolbox_amd/csrc/gemm_gram.hip \
 //         dgp-toolbox_amd/csrc/gemm_tall.hip dgp-toolbox_amd/csrc/gemm_tallu.hip dgp-toolbox_amd/csrc/gemm_small.hip \
 //         dgp-toolbox_amd/csrc/gemm_mid.hip -o tools/tall_bench
-//   tools/tall_bench [rows] [reps] [D] [which: bitmask 1 T/NT, 2 T/plain, 4 T/no store, 8 dC, 16 Gram, 32 g row-panel]
+//   tools/tall_bench [rows] [reps] [D] [which: bitmask 1 T/NT, 2 T/plain, 4 T/no store, 8 dC, 16 Gram, 32 g row-panel, 64 dC row-panel]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +17,7 @@
 #include <functional>
 #include "gemm_tall.h"
 #include "gemm_tallu.h"
+#include "gemm_dcpanel.h"
 #include "dgp_internal.h"
 using namespace dgp;
 
@@ -110,6 +111,15 @@ int main(int argc, char** argv) {
       const float t = time_ms(st, reps, [&]() { CK(gemm_f64(st, GEMM_TN, a)); });
       printf("G_d = sum_p v_pd c_p c_pT (Gram kernel)   %8.3f ms  %5.1f TFLOP/s algorithmic\n", t, flopsT / t / 1e9);
     }
+  }
+  if (which & 64) {
+    DcPanelArgs a{};
+    a.T = T; a.ldt = DM; a.B = WT; a.C = Cb; a.s = vbar; a.as_ld = D; a.eadd = Ct; a.rowf = mbar; a.colf = u; a.rank = D; a.alpha = 2.0; a.P = P; a.D = D;
+    const unsigned gridP = (unsigned)std::min<long>((P + 127) / 128, cus);
+    float t;
+    if (D == 8) t = time_ms(st, reps, [&]() { hipLaunchKernelGGL(dc_panel_kernel<8>, dim3(gridP), dim3(512), 0, st, a); });
+    else t = time_ms(st, reps, [&]() { hipLaunchKernelGGL(dc_panel_kernel<-1>, dim3(gridP), dim3(512), 0, st, a); });
+    printf("dC (row-panel kernel, row-major T)        %8.3f ms  %5.1f TFLOP/s algorithmic\n", t, flopsT / t / 1e9);
   }
   if (which & 32) {
     double* Z1 = dalloc(256 * 9); fill_rand(Z1, 256 * 9, 8);
