@@ -130,6 +130,15 @@ void g_panel_kernel(GPanelArgs g) {
       fa[slot][s8][1] = v[1];
     }
   };
+  // Workgroup barrier for the epilogue's LDS hand-overs.  NOT __syncthreads(): that one waits for vmcnt(0) as well, i.e. for the
+  // next round's E / X1 rows (requested a round ahead precisely so that nobody waits for them) and for the next panel's
+  // operand requests - a memory latency at each of the 24 barriers of a panel (the epilogue was 29 % of the kernel).
+  auto lds_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
   double acc[16][4];
   double gacc[2][3];
 #pragma unroll
@@ -234,7 +243,7 @@ void g_panel_kernel(GPanelArgs g) {
     for (int r = 0; r < 8; ++r) {
 #endif
       const long rrow0 = prow0 + 16 * r;
-      __syncthreads();            // the previous round's reads of sG / sX are done, its partials are complete in sP[(r - 1) & 1]
+      lds_barrier();              // the previous round's reads of sG / sX are done, its partials are complete in sP[(r - 1) & 1]
       if (r > 0 && tid < 16 * W && rrow0 - 16 + xp < g.P) {
         const double* p = sP + ((r - 1) & 1) * (8 * 64 * 3) + r1_lane * 3 + r1_e;
         g.R1[(rrow0 - 16 + xp) * W + xj] = ((p[0 * 192] + p[1 * 192]) + (p[2 * 192] + p[3 * 192])) + ((p[4 * 192] + p[5 * 192]) + (p[6 * 192] + p[7 * 192]));
@@ -251,14 +260,14 @@ void g_panel_kernel(GPanelArgs g) {
         sX[xp * 12 + xjj] = xv;
         xv = (r + 1 < 8 && rrow0 + 16 + xp < g.P) ? g.X1[(rrow0 + 16 + xp) * W + xj] : 0.0;
       }
-      __syncthreads();
+      lds_barrier();
       {                           // g = dK .* E in place, then the next round's factor
         d2_t* im = reinterpret_cast<d2_t*>(sG + erow * GP_PITCH + ecol);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) im[32 * q4] = im[32 * q4] * er[q4];
         if (r + 1 < 8) load_Er(rrow0 + 16);
       }
-      __syncthreads();
+      lds_barrier();
       // ---- R1 partial of this wave: columns 32 wave .. 32 wave + 31 of g (k-steps of 4 columns)
       double racc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -293,7 +302,7 @@ void g_panel_kernel(GPanelArgs g) {
         }
       }
     }
-    __syncthreads();              // the last round's partials
+    lds_barrier();                // the last round's partials
     if (tid < 16 * W && prow0 + 112 + xp < g.P) {
       const double* p = sP + (7 & 1) * (8 * 64 * 3) + r1_lane * 3 + r1_e;
       g.R1[(prow0 + 112 + xp) * W + xj] = ((p[0 * 192] + p[1 * 192]) + (p[2 * 192] + p[3 * 192])) + ((p[4 * 192] + p[5 * 192]) + (p[6 * 192] + p[7 * 192]));
