@@ -203,17 +203,24 @@ int fail(dgp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
 inline long round_up(long x, long m) { return ((x + m - 1) / m) * m; }
 
 // ------------------------------------------------------------------------------- profiling helpers
+// Folds the recorded event pairs into the per-category sums and empties the ring.  The pairs were recorded on whatever stream the
+// context was launching on (main stream, chain streams, comm stream): every pair's END event is waited for, not just the current
+// stream, and the ring is emptied whatever happens - round 4 found the bug the hard way: with the ring full (bench.py --steps 300)
+// a pair still running on a side stream made hipEventElapsedTime fail, the early return left `used` at the ring's size and the next
+// scope wrote behind the arrays (segmentation fault).
 int prof_drain(dgp_ctx* ctx) {
   Prof& p = ctx->prof;
   if (p.used == 0) return DGP_OK;
-  HIPCHK(hipStreamSynchronize(ctx->st));
+  int rc = DGP_OK;
   for (size_t i = 0; i < p.used; ++i) {
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
-    p.ms[p.cat[i]] += ms;
+    if (hipEventSynchronize(p.ev[2 * i + 1]) == hipSuccess && hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]) == hipSuccess)
+      p.ms[p.cat[i]] += ms;
+    else
+      rc = fail(ctx, DGP_ERR_HIP, "prof_drain: an event pair could not be read (its time is missing from the profile)");
   }
   p.used = 0;
-  return DGP_OK;
+  return rc;
 }
 
 struct ProfScope {
@@ -234,9 +241,10 @@ struct ProfScope {
         for (size_t i = old; i < p.ev.size(); ++i) (void)hipEventCreate(&p.ev[i]);
         p.cat.resize(p.ev.size() / 2);
       } else {
-        prof_drain(c);
+        (void)prof_drain(c);
       }
     }
+    if (p.used * 2 + 2 > p.ev.size()) { active = false; return; }      // (cannot happen after a drain; never index past the ring)
     slot = p.used++;
     p.cat[slot] = cat;
     p.launches[cat] += 1;

@@ -362,3 +362,36 @@ def test_g_panel_declines_small_inputs(ctx):
     P = 1000
     _, _, used = ctx.dev_g_panel(rng.standard_normal((P, 256)), np.eye(256), np.ones((P, 256)), np.ones((256, 3)), np.ones((P, 3)))
     assert not used
+
+
+def test_profiling_ring_overflow_is_drained_not_overrun():
+    """dgp_prof_*: the ring of HIP-event pairs (8192) is folded into the per-category sums when it fills up.  Round 4 found that
+    `bench.py --steps 300` ended in a segmentation fault: with the ring full, a pair still running on a side stream made the fold
+    return early, the ring stayed full and the next scope wrote behind it.  A three-layer model with Mp = 128 (launch-by-launch
+    chains on side streams, ~50 scopes per iteration) for enough iterations to fill the ring twice."""
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    rng = np.random.default_rng(0)
+    N, D, M = 600, 2, 100
+    X = rng.standard_normal((N, D)); Y = np.sin(X[:, :1]) + 0.1 * rng.standard_normal((N, 1))
+    m = DGP(X, Y, X[:M].copy(), [RBF(1.0, np.ones(D)) for _ in range(3)], [2, 2], Gaussian(), num_samples=2)
+    ctx = m._sync_model()
+    ctx.adam_reset()
+    flags = m._trainable_flags()
+    ctx.prof_enable(True)
+
+    def run(n):
+        for _ in range(n):
+            c = m._grad_step(m.data)
+            c.adam_step(0.01, 0.9, 0.999, 1e-7, flags)
+        ctx.sync()
+        return ctx.prof_read()                  # (reading folds the ring and resets the sums)
+
+    per_it = sum(v["launches"] for v in run(50).values()) / 50.0
+    assert per_it > 5
+    prof = run(int((2 * 8192 + 1000) / per_it) + 1)
+    ctx.prof_enable(False)
+    m._device_newer = True
+    assert sum(v["launches"] for v in prof.values()) > 2 * 8192
+    assert all(np.isfinite(v["ms"]) and v["ms"] >= 0 for v in prof.values()) and prof["small_matrix_chain"]["ms"] > 0
+    assert np.isfinite(ctx.last_elbo())
