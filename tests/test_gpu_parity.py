@@ -909,6 +909,72 @@ def test_propagate_vjp_philox_replay_and_finite_difference():
     assert abs(fd - float((grad * d).sum())) < 1e-6 * max(1.0, abs(fd))
 
 
+def test_matern_layers_at_256_inducing_points_against_oracle():
+    """Matern-5/2 / Matern-3/2 layers with 200 (-> 256) inducing points and 4500 sample-points per layer: the backward pass through
+    Kuf multiplies dK by the STORED derivative factor (not by Kuf^T) inside the row-panel kernel (csrc/gemm_gpanel.h), dC runs on
+    csrc/gemm_dcpanel.h.  ELBO and every gradient block against the torch-autograd twin of the oracle."""
+    import dgp_oracle_torch as T
+    from dgp_dace.gpflow_compat import Matern32, Matern52, RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    rng = np.random.default_rng(8)
+    N, D, M, S = 500, 3, 200, 9
+    X = rng.standard_normal((N, D)); Y = np.sin(X[:, :1]) + 0.1 * rng.standard_normal((N, 1))
+    Z = X[rng.permutation(N)[:M]].copy()
+    ks = [(Matern52, O.Matern52, 1.1, 1.3), (Matern32, O.Matern32, 0.9, 0.8), (RBF, O.RBF, 1.0, 1.0)]
+    m = DGP(X, Y, Z, [k(v, l * np.ones(D)) for k, _, v, l in ks], [3, 3], Gaussian(), num_samples=S)
+    mo = O.OracleDGP(X, Y, Z, [ko(v, l * np.ones(D)) for _, ko, v, l in ks], [3, 3], num_samples=S)
+    for l, lo in zip(m.layers, mo.layers):
+        qm = 0.2 * rng.standard_normal(lo.q_mu.shape)
+        qs = 0.3 * lo.q_sqrt
+        l.q_mu.assign(qm); lo.q_mu = qm.copy()
+        l.q_sqrt.assign(qs); lo.q_sqrt = qs.copy()
+    ctx = m._sync_model()
+    m._sync_data(m.data)
+    ctx.grad_partial(S, 3, None)
+    elbo = ctx.grad_finish(want_elbo=True)
+    eo, G = T.elbo_and_grads(mo, O.draw_zs(mo, 3, S, N))
+    assert abs(elbo - eo) < 1e-8 * abs(eo), (elbo, eo)
+    Gp = split_flat(m, ctx.grad_get())
+    for i in range(3):
+        for k in ("Z", "lengthscales", "variance", "q_mu", "q_sqrt"):
+            ref = np.asarray(G["layers"][i][k])
+            got = np.tril(Gp[(i, k)]) if k == "q_sqrt" else Gp[(i, k)]
+            assert np.abs(got - ref).max() < 1e-6 * max(1.0, np.abs(ref).max()), (i, k)
+
+
+def test_propagate_vjp_at_256_inducing_points_uses_the_row_panel_kernel():
+    """The acquisition side at the production kernels' shape (Mp = 256, S x N >= 4096 sample-points): `dgp_propagate_vjp`
+    runs the backward pass without parameter sums, i.e. csrc/gemm_gpanel.h with no GX slab and the dC product on the row-panel
+    kernel; checked by central finite differences of a linear functional of the predictive moments along a random direction,
+    with the Matern-3/2 kernel in the middle layer (the stored derivative factor E, not Kuf^T, multiplies dK there)."""
+    from dgp_dace.gpflow_compat import RBF, Matern32, Gaussian
+    from dgp_dace.models.dgp import DGP
+    rng = np.random.default_rng(21)
+    N, D, M, S = 400, 3, 200, 12
+    X = rng.standard_normal((N, D)); Y = np.sin(X[:, :1]) + 0.1 * rng.standard_normal((N, 1))
+    m = DGP(X, Y, X[:M].copy() + 0.01 * rng.standard_normal((M, D)), [RBF(1.2, 0.9 * np.ones(D)), Matern32(0.8, 1.1 * np.ones(D)),
+            RBF(1.0, np.ones(D))], [3, 3], Gaussian(), num_samples=S, seed=4)
+    for l in m.layers:
+        l.q_mu.assign(0.3 * rng.standard_normal(l.q_mu.shape))
+        l.q_sqrt.assign(0.5 * np.asarray(l.q_sqrt.numpy()))
+    Xn = rng.standard_normal((N, D))
+    a, b = rng.standard_normal((N, 1)), rng.standard_normal((N, 1))
+
+    def objective(Xq, seed):
+        m._eval_count = seed - m.seed
+        Fm, Fv = m.predict_f(Xq, S=S)
+        return float((a * Fm.mean(0)).sum() + (b * Fv.mean(0)).sum()), Fm, Fv
+
+    seed = m.seed + 77
+    f0, Fm, Fv = objective(Xn, seed)
+    grad = m.propagate_vjp(Xn, S=S, mean_bar=np.broadcast_to(a / S, Fm.shape).copy(), var_bar=np.broadcast_to(b / S, Fv.shape).copy())
+    assert grad.shape == Xn.shape and np.all(np.isfinite(grad))
+    d = rng.standard_normal(Xn.shape)
+    h = 1e-5
+    fd = (objective(Xn + h * d, seed)[0] - objective(Xn - h * d, seed)[0]) / (2 * h)
+    assert abs(fd - float((grad * d).sum())) < 2e-6 * max(1.0, abs(fd)), (fd, float((grad * d).sum()))
+
+
 def test_propagate_vjp_single_layer_model():
     """One SVGP layer (num_units=[]): the layer is shared by all samples, cotangents are summed over S."""
     import dgp_oracle_torch as OT
