@@ -37,6 +37,104 @@ constexpr int LEAF = 64;
 // LF = 64: the leaf of the recursion.  LF = 32: models with at most 32 inducing points (the Bayesian-optimisation
 // surrogates; Mp = 64 with an identity padding): a quarter of the dependent readlane / fma chain (57 -> 16 us), the padding
 // rows [n, npad) of X are written as identity rows.
+// LF = 64 on FOUR waves (round 4).  The one-wave leaf above walks 2 x 2016 dependent (v_readlane, fma) pairs: 52 us, and four leaves
+// sit on the critical path of every Kuu factorisation - at the head of every iteration, where nothing can overlap them.  Here thread
+// (row i = t % 64, column group q = t / 64) keeps a[m] = A[i][q + 4 m]: a column step costs 16 FMAs per thread instead of up to 63;
+// the column being eliminated travels through LDS (double buffered: one barrier per step), a row of X' through v_readlane inside
+// each wave.  Every element sees the same FMAs in the same order as in the one-wave leaf: the results are bit-identical.
+template <int B, int E, class F>
+__device__ __forceinline__ void sm_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    sm_static_for<B + 1, E>(f);
+  }
+}
+template <int Q>
+__device__ __forceinline__ void leaf64_coop_body(double* __restrict__ A, double* __restrict__ X, int ld, int n, int do_chol, int* info,
+                                                 double (&T)[64][65], double* Lc, double* Dg) {
+  const int tid = threadIdx.x, i = tid & 63;
+  double a[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int j = Q + 4 * m;
+    const double v = T[i][j];
+    a[m] = (i < n && j < n) ? (j <= i ? v : 0.0) : (i == j ? 1.0 : 0.0);     // rows and columns beyond n: an identity block
+  }
+  if (do_chol) {
+    bool bad = false;
+    sm_static_for<0, 64>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value, qc = c & 3, mc = c >> 2;
+      if constexpr (Q == qc) {
+        const double piv = lane_bcast(a[mc], c);
+        // 1/sqrt(pivot): hardware estimate + two Newton steps (as the one-wave leaf)
+        double rs = __builtin_amdgcn_rsq(piv);
+        rs = rs * (1.5 - 0.5 * piv * rs * rs);
+        rs = rs * (1.5 - 0.5 * piv * rs * rs);
+        if (!(piv > 0.0)) { rs = nan(""); bad = true; }
+        const double l = (i >= c) ? a[mc] * rs : 0.0;       // column c of L (zero above the diagonal)
+        a[mc] = l;
+        Lc[(c & 1) * 64 + i] = l;
+        if (i == c) Dg[c] = l;
+      }
+      __syncthreads();
+      const double li = Lc[(c & 1) * 64 + i];
+#pragma unroll
+      for (int m = 0; m < 16; ++m)
+        if (Q + 4 * m > c) a[m] = fma(-li, Lc[(c & 1) * 64 + Q + 4 * m], a[m]);   // only j <= i is meaningful
+    });
+    if (bad && i == 0) atomicOr(info, 1);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 16; ++m) T[i][Q + 4 * m] = a[m];
+    __syncthreads();
+    for (int r = tid >> 6; r < n; r += 4)
+      if (i < n) A[(long)r * ld + i] = T[r][i];
+  }
+  __syncthreads();
+  const double dinv = 1.0 / Dg[i];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) a[m] = (i > Q + 4 * m) ? a[m] * dinv : 0.0;      // strictly lower part of L' = D^-1 L
+  sm_static_for<0, 64>([&](auto kc) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value, qk = k & 3, mk = k >> 2;
+    if constexpr (Q == qk) Lc[(k & 1) * 64 + i] = a[mk];                        // L'[i][k] for the rows below k, 0 for the others
+    __syncthreads();
+    const double mi = Lc[(k & 1) * 64 + i];
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+      if (Q + 4 * m < k) a[m] = fma(-mi, lane_bcast(a[m], k), a[m]);          // row k of X' is final in lane k of every wave
+    if constexpr (Q == qk) a[mk] = -mi;
+  });
+  __syncthreads();
+  if (tid < 64) Lc[tid] = dinv;                // (1 / diagonal per row, for the columns)
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int j = Q + 4 * m;
+    T[i][j] = (i > j) ? a[m] * Lc[j] : (i == j ? dinv : 0.0);
+  }
+  __syncthreads();
+  for (int r = tid >> 6; r < n; r += 4)
+    if (i < n) X[(long)r * ld + i] = T[r][i];
+}
+
+__global__ __launch_bounds__(256) void leaf64_coop_kernel(double* Aall, double* Xall, int ld, long stride, int off, int n, int do_chol, int* info) {
+  __shared__ double T[64][65];
+  __shared__ double Lc[128];
+  __shared__ double Dg[64];
+  double* A = Aall + (long)blockIdx.x * stride + (long)off * ld + off;
+  double* X = Xall + (long)blockIdx.x * stride + (long)off * ld + off;
+  const int tid = threadIdx.x, i = tid & 63;
+  for (int r = tid >> 6; r < 64; r += 4) T[r][i] = (r < n && i < n) ? A[(long)r * ld + i] : 0.0;
+  if (tid < 64) Dg[tid] = (tid < n) ? A[(long)tid * ld + tid] : 1.0;       // (the diagonal of L when only the inverse is wanted)
+  __syncthreads();
+  switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
+    case 0: leaf64_coop_body<0>(A, X, ld, n, do_chol, info, T, Lc, Dg); break;
+    case 1: leaf64_coop_body<1>(A, X, ld, n, do_chol, info, T, Lc, Dg); break;
+    case 2: leaf64_coop_body<2>(A, X, ld, n, do_chol, info, T, Lc, Dg); break;
+    default: leaf64_coop_body<3>(A, X, ld, n, do_chol, info, T, Lc, Dg); break;
+  }
+}
+
 // batched strided block copy: dst[b][r][c] = src[b][r][c] for an nr x nc block (leading dimension ld, batch stride)
 static hipError_t sub_gemm(hipStream_t st, GemmOp op, long M, long N, long K, const double* A, const double* B, double* C,
                            int ld, long stride, int batch, double alpha, int beta, long sA = -1, long sB = -1) {
@@ -52,6 +150,12 @@ static hipError_t potrf_inv_rec(hipStream_t st, double* A, double* X, double* tm
                                 int n, int do_chol, int* info) {
   hipError_t e;
   if (n <= LEAF) {
+    static int coop = -1;
+    if (coop < 0) { const char* e = getenv("DGP_LEAF_COOP"); coop = e ? atoi(e) : 1; }
+    if (coop && !chain_recorder()) {      // (a recorded chain replays the one-wave body: chain.h)
+      hipLaunchKernelGGL(leaf64_coop_kernel, dim3(batch), dim3(256), 0, st, A, X, ld, stride, off, n, do_chol, info);
+      return hipGetLastError();
+    }
     (void)chain_launch<leaf_potrf_inv_64_kernel>(st, dim3(batch), A, X, ld, stride, off, n, do_chol, info, 0);
     return hipGetLastError();
   }
