@@ -4,9 +4,11 @@
 // with W_d^T upper triangular (k <= n inside each 256 x 256 block), T row-major [rows][D * 256].
 // Why beside gemm_tallu.h: that kernel's unit is (256-row tile, 128-column half), so the left halves read the first 128
 // columns of every T_d a second time (T is read 1.5 times: 26 GB of the iteration's 94 GB), its A operand goes through LDS
-// (4 of its 6 LDS-DMA requests per wave and k-tile, two thirds of its stage) and it ran at MfmaUtil 0.77.  The k-tile stream
-// of gemm_gpanel.h - a wave owns 16 rows across all 256 columns, its A fragments come straight from global memory into
-// registers, only B goes through LDS - ran at 0.85 in isolation (profiles/r4_gpanel_pmc.txt), and reads every operand once.
+// (4 of its 6 LDS-DMA requests per wave and k-tile, two thirds of its stage) and its units - a tile x half x ALL D blocks - are
+// coarse: 488 row tiles of a rank's share of 8 GPUs leave most of the 256 CUs one unit behind.  The k-tile stream of
+// gemm_gpanel.h - a wave owns 16 rows across all 256 columns, its A fragments come straight from global memory into registers,
+// only B goes through LDS - reads every operand once and deals 128-row panels.  Measured (profiles/r4_dcpanel.txt): a tie at
+// 10^6 rows, 10 % faster at 125 000 - 250 000 rows: the dispatcher uses this kernel between 4096 and 300 000 rows.
 //
 // Shape.  One persistent workgroup per CU (8 waves), 128-row panels dealt round-robin.  A panel is D segments of sixteen
 // k-tiles (16 rows of W_d^T each, t = 0 .. 15: the k-tile meets the column blocks j >= t, the long k-tiles come first); the
@@ -19,8 +21,9 @@
 //   * One barrier per k-tile, in the MIDDLE of it (gemm_gram.h's arrangement): it publishes k-tile n + 1 (whose requests went
 //     out two k-tiles earlier; every wave waits for its own pieces first, counted) and certifies that every wave has left
 //     k-tile n - 1, whose stage and ring slot take the requests for k-tile n + 3 right behind it.  The fragment reads run
-//     two units ahead across the k-tile boundary: no drain, no bubble at the boundary (a first version with the barrier at
-//     the top of the k-tile lost ~1200 cycles per k-tile and was no faster than gemm_tallu.h).
+//     two units ahead across the k-tile boundary: no drain at the boundary.  (Measured against a first version with the barrier
+//     at the top of the k-tile: the same time - the stream's ~1000 cycles per k-tile beyond its MFMAs are not the barrier;
+//     fragments four units ahead: the same again.  NOTES.md 13.5.)
 //   * Epilogue once per panel: the rank-D term as two more k-steps on the matrix cores (as gemm_tallu.h), then
 //     dC = acc - esc * Ct, 32 buffer stores per lane; the next panel's first three k-tiles are already in flight.
 // Rows past P read as zeros (buffer resources end at the operand's last row) and are not stored.
