@@ -332,7 +332,8 @@ def test_one_rocm_stack_in_the_normal_load_order(ctx):
     assert paths == _native.hip_runtimes_in(open("/proc/self/maps"))
 
 
-@pytest.mark.parametrize("P,w1", [(49280, 9), (12496, 9), (100001, 9), (4224, 2), (20000, 5)])
+@pytest.mark.parametrize("P,w1", [(49280, 9), (12496, 9), (100001, 9), (4224, 2), (20000, 5), (4097, 3), (8200, 4), (6000, 6),
+                                  (33000, 7), (5000, 8)])
 def test_g_panel_kernel_every_element_against_numpy(ctx, P, w1):
     """csrc/gemm_gpanel.h, the launch that replaces `g = (Cbar Linv) .* k`, `g [Z | 1]` and `g^T [X | 1]` of the backward pass
     through Kuf (what tf.GradientTape derives for layers.py:243 under dgp.py:272-275) at 256 inducing
