@@ -322,9 +322,7 @@ void g_panel_kernel(GPanelArgs g) {
   }
 }
 
-bool g_panel_ok(int Mp, int w1, long P);
-long g_panel_ws_doubles();
-hipError_t g_panel(hipStream_t st, const double* Cbar, const double* Linv, const double* E, long P, const double* Z1,
-                   const double* X1, int w1, double* R1, double* GX, double* ws, int cu_count, int reserve_cus);
+// host side: g_panel_ok / g_panel (gemm_gpanel.hip, declared in dgp_internal.h); the slab scratch is the one of points.hip's
+// one-pass contraction (rbf_bwd_contract_ws_doubles: 512 slabs of 256 x 9)
 
 }  // namespace dgp

@@ -14,8 +14,6 @@ bool g_panel_ok(int Mp, int w1, long P) {
   return enabled && Mp == 256 && w1 >= 2 && w1 <= 9 && P >= min_p;
 }
 
-long g_panel_ws_doubles() { return 512L * 256 * 9; }      // (the scratch of points.hip's one-pass contraction has this size)
-
 // R1 [P x w1] = g [Z | 1] and, with GX, GX [256 x w1] += g^T [X | 1] for g = (Cbar Linv) .* E, g never stored
 hipError_t g_panel(hipStream_t st, const double* Cbar, const double* Linv, const double* E, long P, const double* Z1,
                    const double* X1, int w1, double* R1, double* GX, double* ws, int cu_count, int reserve_cus) {
