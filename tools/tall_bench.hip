@@ -7,7 +7,7 @@
 //         dgp-toolbox_amd/csrc/gemm_f64.hip dgp-toolbox_amd/csrc/gemm_wide.hip dgp-toolbox_amd/csrc/gemm_gram.hip \
 //         dgp-toolbox_amd/csrc/gemm_tall.hip dgp-toolbox_amd/csrc/gemm_tallu.hip dgp-toolbox_amd/csrc/gemm_small.hip \
 //         dgp-toolbox_amd/csrc/gemm_mid.hip -o tools/tall_bench
-//   tools/tall_bench [rows] [reps] [D] [which: bitmask 1 T/NT, 2 T/plain, 4 T/no store, 8 dC, 16 Gram, 32 g row-panel, 64 dC row-panel]
+//   tools/tall_bench [rows] [reps] [D] [which: bitmask 1 T/NT, 2 T/plain, 4 T/no store, 8 dC, 16 Gram, 32 g row-panel, 64 dC row-panel, 128 Gram two sources]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -110,6 +110,18 @@ int main(int argc, char** argv) {
     else {
       const float t = time_ms(st, reps, [&]() { CK(gemm_f64(st, GEMM_TN, a)); });
       printf("G_d = sum_p v_pd c_p c_pT (Gram kernel)   %8.3f ms  %5.1f TFLOP/s algorithmic\n", t, flopsT / t / 1e9);
+    }
+  }
+  if (which & 128) {
+    // two-source form (rows from Cb, columns from Ct: one 256 x 256 lower triangle of a rectangular block of a 512 x 512 Gram matrix)
+    GemmArgs a{};
+    a.gram_ws = ws; a.gram_ws_bytes = gemm_gram_ws_bytes(0);
+    a.A = Cb; a.B = Ct; a.C = G; a.lda = a.ldb = a.ldc = 256; a.M = a.N = 256; a.K = P; a.batch = 1;
+    a.alpha = 1.0; a.beta = 1; a.tri = TRI_OUT_LOWER; a.triblk = 256; a.splits = 1;
+    if (!gemm_gram_ok(a)) printf("Gram, two sources: not eligible\n");
+    else {
+      const float t = time_ms(st, reps, [&]() { CK(gemm_f64(st, GEMM_TN, a)); });
+      printf("G = A^T C lower triangle, two sources     %8.3f ms  %5.1f TFLOP/s algorithmic\n", t, (double)P * 256.0 * 257.0 / t / 1e9);
     }
   }
   if (which & 64) {
