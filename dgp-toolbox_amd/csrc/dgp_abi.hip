@@ -1166,6 +1166,8 @@ int dgp_prof_enable(dgp_ctx* ctx, int32_t on) {
   RET(prof_drain(ctx));
   Prof& p = ctx->prof;
   p.on = on != 0;
+  p.mask = (on & 0x100) ? (unsigned)(on & 0xF) : 0xFu;
+  p.depth = 0;
   for (int c = 0; c < kNCat; ++c) { p.ms[c] = p.flops[c] = p.bytes[c] = 0; p.launches[c] = 0; }
   return DGP_OK;
 }

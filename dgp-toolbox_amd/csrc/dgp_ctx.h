@@ -58,6 +58,7 @@ struct Layer {
 constexpr int kNCat = 4;
 struct Prof {
   bool on = false;
+  unsigned mask = 0xFu;               // categories whose scopes record events (dgp_prof_enable); the others only count flops / launches
   int depth = 0;
   std::vector<hipEvent_t> ev;
   std::vector<int> cat;
@@ -225,13 +226,18 @@ int prof_drain(dgp_ctx* ctx) {
 
 struct ProfScope {
   dgp_ctx* ctx;
-  bool active;
+  bool active, counted;
   size_t slot;
-  ProfScope(dgp_ctx* c, int cat, double flops, double bytes) : ctx(c), active(false), slot(0) {
+  ProfScope(dgp_ctx* c, int cat, double flops, double bytes) : ctx(c), active(false), counted(false), slot(0) {
     Prof& p = c->prof;
     if (!p.on || chain_recorder()) return;
     p.flops[cat] += flops;
     p.bytes[cat] += bytes;
+    if (!((p.mask >> cat) & 1u)) {      // a category that is not being timed: no event pair
+      if (p.depth == 0) p.launches[cat] += 1;
+      return;
+    }
+    counted = true;
     if (p.depth++ > 0) return;          // nested scopes are covered by the outermost one
     active = true;
     if (p.used * 2 + 2 > p.ev.size()) {
@@ -252,7 +258,7 @@ struct ProfScope {
   }
   ~ProfScope() {
     Prof& p = ctx->prof;
-    if (!p.on || chain_recorder()) return;
+    if (!p.on || !counted || chain_recorder()) return;
     if (active) (void)hipEventRecord(p.ev[2 * slot + 1], ctx->st);
     if (p.depth > 0) --p.depth;
   }

@@ -34,7 +34,14 @@ struct TallArgs {
   long M;                        // rows, a multiple of 128 (the last tile may be half empty)
   int D;
   int rowmajor;                  // T as a plain [M][ldc] array (read back by gemm_dcpanel.h) instead of the blocked layout
+#ifdef TL_TIMING
+  unsigned* ts;                  // (diagnostic build, tools/tall_bench only) [workgroup][TL_TS_PER_WG]: per position of every pair, shader
+                                 // clocks from the previous barrier to this position's wait, and inside the wait + barrier
+#endif
 };
+#ifdef TL_TIMING
+constexpr int TL_TS_PER_WG = 160 * 48;
+#endif
 
 // position p = 0..23 inside a (row tile, d) pair: p < 16: left half (h = 0), k-tile t = p, blocks 0..min(p, 7);
 // p >= 16: right half (h = 1), k-tile t = p - 8, blocks 0..p - 16
@@ -48,11 +55,20 @@ constexpr int tl_nact(int p) { return p < 16 ? (p < 7 ? p : 7) + 1 : p - 15; }
 // the stores issued since.  All compile-time: the first pair issues the same (zero) stores as any other.
 constexpr int tl_pre(int p) { return (p <= 6 || (p >= 16 && p <= 22)) ? 4 : 0; }
 constexpr int tl_post(int p) { return (p == 15 || p == 23) ? 4 : 0; }
-#ifdef TL_STORE_AFTER
-// (variant: the deferred stores of a position are issued BEHIND its DMA request, so they are younger than it and the wait two
-//  positions later does not have to see them retired: one more k-tile of slack for the stores of the short ramp k-tiles)
+#ifndef TL_STORE_SPREAD
+#define TL_STORE_SPREAD 0
+#endif
+#if TL_STORE_SPREAD
+// Spread form (NOT the default - measured slower): the four stores of a deferred column issued one by one BETWEEN the MFMA units of
+// its position, in front of the position's wait.  Why it was tried: the clock records of the diagnostic build (TL_TIMING) show ~800
+// clocks per storing position in which all eight waves queue their stores behind the barrier and none issues an MFMA.  What it
+// did: 170 k instead of 177 k clocks per pair - and 10.18 instead of 9.69 ms, because with the stores the kernel runs at the
+// package power limit (1355 W) and the spread form is clocked at 2.10 instead of 2.28 GHz there (profiles/r4_power.txt, NOTES.md
+// 13.6).  Program order of a position p:
+// S(p) .. wait(p) .. barrier .. request(p + 3) .. [column 0's stores P(p) behind positions 15 and 23]; younger than the requests
+// wait(p) is for (issued at p - 2): P(p - 2), S(p - 1), the requests of p - 1, P(p - 1), S(p).
 constexpr int tl_allow(int p) {
-  return 6 + tl_pre((p + 22) % 24) + tl_post((p + 22) % 24) + tl_pre((p + 23) % 24) + tl_post((p + 23) % 24);
+  return 6 + tl_post((p + 22) % 24) + tl_pre((p + 23) % 24) + tl_post((p + 23) % 24) + tl_pre(p);
 }
 #else
 constexpr int tl_allow(int p) { return 6 + tl_post((p + 22) % 24) + tl_pre((p + 23) % 24) + tl_post((p + 23) % 24); }
@@ -173,42 +189,41 @@ void gemm_tall_kernel(TallArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) vo[i] = (unsigned)(((long)(i * 16 + 4 * (li >> 2) + lk) * g.ldc + 4 * (li & 3)) * 8);
   } else {
-#ifdef TL_STORE_SECTOR
-  // (timing experiment only - the layout the consumers read is the other one: a lane's two 16-byte stores 64 bytes apart, so
-  //  that ONE store instruction fills whole 32-byte sectors: [c0 e01][c1 e01][c2 e01][c3 e01] | [c0 e23] ...)
-  for (int i = 0; i < 2; ++i) vo[i] = (unsigned)((((wave & 3) * 32 + i * 16 + 4 * (li >> 2) + lk) * 16 + 2 * (li & 3)) * 8);
-#else
 #pragma unroll
   for (int i = 0; i < 2; ++i) vo[i] = (unsigned)((((wave & 3) * 32 + i * 16 + 4 * (li >> 2) + lk) * 16 + 4 * (li & 3)) * 8);
-#endif
   }
   typedef unsigned u4_t __attribute__((ext_vector_type(4)));
   typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-  auto flush = [&](auto jc, unsigned tm, unsigned d, int h, bool last_block) __attribute__((always_inline)) {
-    constexpr int j = decltype(jc)::value;
+  // PART -1: the whole epilogue of the column at once.  PART 0..3 (spread form): store PART alone (row block PART / 2, 16-byte half
+  // PART % 2); the sums of squares (and, for the half's last column, the row sums' own stores) ride on part 0, the accumulators
+  // restart from zero behind part 3.
+  auto flush = [&](auto jc, unsigned tm, unsigned d, int h, bool last_block, auto partc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value, PART = decltype(partc)::value;
     // rows of a half-empty last tile are neither stored nor summed: their stores go through a resource of zero records
     const int nrec = ((long)tm * 256 + wave * 32 < g.M) ? 0x7ffffff0 : 0;
+    if constexpr (PART <= 0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) rsum[i] += acc[i][j][e] * acc[i][j][e];
+        for (int e = 0; e < 4; ++e) rsum[i] += acc[i][j][e] * acc[i][j][e];
 #ifndef TL_DBG_NORS
-    if (last_block) {
-      int li2 = lane & 15, lk2 = lane >> 4;
-      asm volatile("" : "+v"(li2), "+v"(lk2));
-      double* rs = g.rowsq + ((long)d * 2 + h) * g.rowsq_ld + (long)tm * 256 + wave * 32;
-      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(rs, 0, nrec, 0x00020000);
+      if (last_block) {
+        int li2 = lane & 15, lk2 = lane >> 4;
+        asm volatile("" : "+v"(li2), "+v"(lk2));
+        double* rs = g.rowsq + ((long)d * 2 + h) * g.rowsq_ld + (long)tm * 256 + wave * 32;
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(rs, 0, nrec, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        double t = rsum[i];
-        t += __shfl_xor(t, 1);
-        t += __shfl_xor(t, 2);
-        // (the four lanes of a quad hold the same sum and write it to the same address: no divergence)
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, t), rr, (unsigned)((i * 16 + 4 * (li2 >> 2) + lk2) * 8), 0, 0);
-        rsum[i] = 0.0;
+        for (int i = 0; i < 2; ++i) {
+          double t = rsum[i];
+          t += __shfl_xor(t, 1);
+          t += __shfl_xor(t, 2);
+          // (the four lanes of a quad hold the same sum and write it to the same address: no divergence)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, t), rr, (unsigned)((i * 16 + 4 * (li2 >> 2) + lk2) * 8), 0, 0);
+          rsum[i] = 0.0;
+        }
       }
-    }
 #endif
+    }
     if constexpr (STORE) {
       // blocked T: panel (2 tm + w / 4) of 128 rows, 16-column block 16 d + 8 h + j; the block offset sits in the
       // resource base, the instruction's scalar offset stays 0 (gemm_wide.h: store / data-register hazard).  The
@@ -220,34 +235,33 @@ void gemm_tall_kernel(TallArgs g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const d2_t v0 = {acc[i][j][0], acc[i][j][1]}, v1 = {acc[i][j][2], acc[i][j][3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v0), rc, vo[i], 0, NT ? 2 : 0);
-#ifdef TL_STORE_SECTOR
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v1), rc, vo[i] + 64, 0, NT ? 2 : 0);
-#else
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v1), rc, vo[i] + 16, 0, NT ? 2 : 0);
-#endif
+        if (PART < 0 || PART == 2 * i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v0), rc, vo[i], 0, NT ? 2 : 0);
+        if (PART < 0 || PART == 2 * i + 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v1), rc, vo[i] + 16, 0, NT ? 2 : 0);
       }
     }
     // The accumulators of the column restart from zero.  Written HERE by explicit moves: the MFMAs are inline asm (hipcc
     // sees no MFMA), and a plain `acc = 0.0` is materialised as a v_mov right in front of the first MFMA that uses it -
     // without the wait states a VALU write needs before an MFMA reads it as its accumulator (the MFMA then added to the
     // register's stale content: a B fragment; found as errors of one 4-k partial sum in acc[1][j][1] of some columns).
+    if constexpr (PART < 0 || PART == 3) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 4; ++e) {
 #ifdef TL_BUILTIN_MFMA
-        acc[i][j][e] = 0.0;
+          acc[i][j][e] = 0.0;
 #else
-        double z_;
-        asm volatile("v_mov_b64 %0, 0" : "=v"(z_));
-        acc[i][j][e] = z_;
+          double z_;
+          asm volatile("v_mov_b64 %0, 0" : "=v"(z_));
+          acc[i][j][e] = z_;
 #endif
-      }
+        }
 #ifndef TL_BUILTIN_MFMA
-    asm volatile("s_nop 7" ::: "memory");
+      asm volatile("s_nop 7" ::: "memory");
 #endif
+    }
   };
+  constexpr std::integral_constant<int, -1> whole{};
 
   // ---- prologue: three k-tiles requested, the first one landed and published, its first fragments requested
   struct Pair { unsigned lin, tm, d; };
@@ -264,25 +278,21 @@ void gemm_tall_kernel(TallArgs g) {
   unsigned ptm = cons.tm, pd = cons.d;
   issue(std::integral_constant<int, 0>{}, scur, 0);
   issue(std::integral_constant<int, 1>{}, scur, 1);
-#ifdef TL_STORE_AFTER
-  // (what position 22 of a previous pair would have issued behind the request for k-tile 1: zeros into this pair's own left
-  //  half, overwritten at this pair's position 22)
-  flush(std::integral_constant<int, 7>{}, ptm, pd, 0, false);
-#endif
   issue(std::integral_constant<int, 2>{}, scur, 2);
   // the stores a previous pair would have issued behind its last request: zeros into this pair's own right half, which
   // the pair overwrites later (the wave's stores to one address complete in order)
-  flush(std::integral_constant<int, 0>{}, ptm, pd, 1, false);
-#ifdef TL_STORE_AFTER
-  if constexpr (STORE) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-#else
+  flush(std::integral_constant<int, 0>{}, ptm, pd, 1, false, whole);
   if constexpr (STORE) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-#endif
   __builtin_amdgcn_s_barrier();
   readA(0);
   readB(0, uoff(0, 0));
   readB(1, uoff(0, 1));
 
+#ifdef TL_TIMING
+  unsigned ts_off = (unsigned)((blockIdx.x * 8 + wave) * TL_TS_PER_WG * 4);      // (every wave writes its own record: no branch)
+  unsigned long t_b;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_b));
+#endif
   // (ptm, pd): the pair whose right half's block columns 1..7 are still in their registers (the first time: zeros,
   // written to this pair's own right half)
   for (;;) {
@@ -296,16 +306,29 @@ void gemm_tall_kernel(TallArgs g) {
           // first A fragments, the block column due in this k-tile, and the request for the k-tile three ahead into the
           // stage just released
           __builtin_amdgcn_sched_barrier(0);
-#ifdef TL_DBG_FLUSHALL
-          constexpr int allow = 6;
-#else
-          constexpr int allow = STORE ? tl_allow(p) : 6;
+#ifdef TL_TIMING
+          unsigned long t_a;
+          // (the wait INSIDE the statement: the compiler takes an asm output as written at once and may spill or reuse the pair
+          //  while the scalar cache is still about to write it - found as a memory fault through a clobbered descriptor)
+          asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_a));
 #endif
-          static_assert(allow == 6 || allow == 10 || allow == 14, "vmcnt classes");
-          if constexpr (allow == 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+          constexpr int allow = STORE ? tl_allow(p) : 6;
+          static_assert(allow == 6 || allow == 10 || allow == 14 || allow == 18, "vmcnt classes");
+          if constexpr (allow == 18) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
+          else if constexpr (allow == 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
           else if constexpr (allow == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
+#ifdef TL_TIMING
+          {
+            // raw low words: [2 i] = clock at the wait of position i, [2 i + 1] = clock behind the barrier of position i - 1
+            const unsigned lo_a = (unsigned)t_a, lo_b = (unsigned)t_b;
+            const unsigned o1 = ts_off + 4;
+            asm volatile("s_store_dword %0, %2, %3\n\ts_store_dword %1, %2, %4" :: "s"(lo_a), "s"(lo_b), "s"(g.ts), "s"(ts_off), "s"(o1) : "memory");
+            ts_off += 8;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_b));
+          }
+#endif
           // (opaque: 24 positions are a whole number of trips round the ring, so the compiler knows every stage of the
           //  straight-line body, turns the fragment addresses into base + constants beyond the 16-bit offset field and
           //  keeps dozens of them in registers)
@@ -318,17 +341,14 @@ void gemm_tall_kernel(TallArgs g) {
           readA(0);
           // block column (p % 16) + 1 ... of the tile finished before this one: positions 0..6 (the previous pair's
           // right half, if any) and 16..22 (this pair's left half)
-#if !defined(TL_DBG_FLUSHALL) && !defined(TL_STORE_AFTER)
-          if constexpr (p <= 6) flush(std::integral_constant<int, p + 1>{}, ptm, pd, 1, p == 6);
-          if constexpr (p >= 16 && p <= 22) flush(std::integral_constant<int, p - 15>{}, cons.tm, cons.d, 0, p == 22);
-#endif
+          // (with stores in the spread form the column has gone out part by part between the units above)
+          if constexpr (!(STORE && TL_STORE_SPREAD)) {
+            if constexpr (p <= 6) flush(std::integral_constant<int, p + 1>{}, ptm, pd, 1, p == 6, whole);
+            if constexpr (p >= 16 && p <= 22) flush(std::integral_constant<int, p - 15>{}, cons.tm, cons.d, 0, p == 22, whole);
+          }
           // the k-tile three ahead: position p + 3 of this pair, or of the workgroup's next pair
           if constexpr (p + 3 < 24) issue(std::integral_constant<int, p + 3>{}, scur, stage);
           else issue(std::integral_constant<int, p + 3 - 24>{}, snxt, stage);
-#if !defined(TL_DBG_FLUSHALL) && defined(TL_STORE_AFTER)
-          if constexpr (p <= 6) flush(std::integral_constant<int, p + 1>{}, ptm, pd, 1, p == 6);
-          if constexpr (p >= 16 && p <= 22) flush(std::integral_constant<int, p - 15>{}, cons.tm, cons.d, 0, p == 22);
-#endif
           stage = stage == TL_NSTAGE - 1 ? 0 : stage + 1;
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -349,23 +369,26 @@ void gemm_tall_kernel(TallArgs g) {
             acc[i][j][e] = c_;
 #endif
           }
+        // spread form: store k of the deferred column behind unit k (U - 2) / 4 - all four in front of the position's wait
+        if constexpr (STORE && TL_STORE_SPREAD && tl_pre(p) != 0) {
+          w_static_for<0, 4>([&](auto kc) __attribute__((always_inline)) {
+            if constexpr (u == decltype(kc)::value * (U - 2) / 4) {
+              if constexpr (p <= 6) flush(std::integral_constant<int, p + 1>{}, ptm, pd, 1, p == 6, kc);
+              else flush(std::integral_constant<int, p - 15>{}, cons.tm, cons.d, 0, p == 22, kc);
+            }
+          });
+        }
         __builtin_amdgcn_sched_barrier(0);
       });
       // a 128-column tile is complete: its block column 0 now (the next tile starts on it), the others inside the next
       // tile's k-tiles (above)
       if constexpr (p == 15) {
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // (MFMA results -> VALU / stores: wait states hipcc cannot see)
-        flush(std::integral_constant<int, 0>{}, cons.tm, cons.d, 0, false);
-#ifdef TL_DBG_FLUSHALL
-        w_static_for<1, 8>([&](auto jc) __attribute__((always_inline)) { flush(jc, cons.tm, cons.d, 0, decltype(jc)::value == 7); });
-#endif
+        flush(std::integral_constant<int, 0>{}, cons.tm, cons.d, 0, false, whole);
       }
       if constexpr (p == 23) {
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-        flush(std::integral_constant<int, 0>{}, cons.tm, cons.d, 1, false);
-#ifdef TL_DBG_FLUSHALL
-        w_static_for<1, 8>([&](auto jc) __attribute__((always_inline)) { flush(jc, cons.tm, cons.d, 1, decltype(jc)::value == 7); });
-#endif
+        flush(std::integral_constant<int, 0>{}, cons.tm, cons.d, 1, false, whole);
       }
     });
     ptm = cons.tm; pd = cons.d;
@@ -376,12 +399,13 @@ void gemm_tall_kernel(TallArgs g) {
     snxt = src_of(nxt.tm, nxt.d);
   }
   // the last pair's right half: block columns 1..7
-#ifndef TL_DBG_FLUSHALL
   w_static_for<1, 8>([&](auto jc) __attribute__((always_inline)) {
-    flush(jc, ptm, pd, 1, decltype(jc)::value == 7);
+    flush(jc, ptm, pd, 1, decltype(jc)::value == 7, whole);
   });
-#endif
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef TL_TIMING
+  asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 }
 
 bool gemm_tall_ok(const GemmArgs& a);

@@ -473,14 +473,21 @@ class Context:
         self._chk(self._lib.dgp_device_info(self._h, buf, 256, C.byref(cu), C.byref(mem)))
         return buf.value.decode(), cu.value, mem.value
 
-    def prof_enable(self, on=True):
-        self._chk(self._lib.dgp_prof_enable(self._h, 1 if on else 0))
+    PROF_CATEGORIES = ("mfma_contractions", "per_point_streaming", "small_matrix_chain", "adam")
+
+    def prof_enable(self, on=True, categories=None):
+        """HIP-event timing of the launches by category; `categories` (names) restricts the event pairs to those - the others
+        still count launches and algorithmic flops, their milliseconds read 0."""
+        code = 1 if on else 0
+        if on and categories is not None:
+            code = 0x100 | sum(1 << self.PROF_CATEGORIES.index(c) for c in categories)
+        self._chk(self._lib.dgp_prof_enable(self._h, code))
 
     def prof_read(self):
         ms, fl, by = np.zeros(4), np.zeros(4), np.zeros(4)
         ln = np.zeros(4, dtype=np.int64)
         self._chk(self._lib.dgp_prof_read(self._h, 4, _ptr(ms), ln.ctypes.data_as(C.POINTER(C.c_int64)), _ptr(fl), _ptr(by)))
-        names = ["mfma_contractions", "per_point_streaming", "small_matrix_chain", "adam"]
+        names = self.PROF_CATEGORIES
         return {n: {"ms": ms[i], "launches": int(ln[i]), "alg_flops": fl[i], "alg_bytes": by[i]} for i, n in enumerate(names)}
 
     def prof_mark(self):

@@ -215,6 +215,9 @@ int dgp_natgrad_step(dgp_ctx* ctx, double gamma, const uint8_t* layer_mask);
 /* ---- measurement: HIP-event timing of kernel launches on the context's stream, by category.
  * categories: 0 = fp64-MFMA contractions over points, 1 = per-point streaming kernels,
  *             2 = small-matrix chain (Kuu/Cholesky/KL/backward chain/natgrad), 3 = Adam.             */
+/* on: 0 = off; 1 = every category; 0x100 | mask = only the categories whose bit (1 << category) is set in mask record events -
+ * the others still count launches and algorithmic flops / bytes, their milliseconds read 0.  (A timed region that needs one
+ * category's duration need not put every other launch between events; at config 2 it measured the same either way.)       */
 int dgp_prof_enable(dgp_ctx* ctx, int32_t on);
 int dgp_prof_read(dgp_ctx* ctx, int32_t n_cat, double* ms_out, int64_t* launches_out, double* alg_flops_out,
                   double* alg_bytes_out);   /* synchronises, returns totals since enable, then resets */

@@ -77,6 +77,13 @@ int main(int argc, char** argv) {
   g.A = Ct; g.lda = 256; g.B = W; g.ldb = DM; g.C = T; g.ldc = DM; g.rowsq = rs; g.rowsq_ld = P; g.M = P; g.D = D;
   const long ntile = ((P + 255) / 256) * D;
   const unsigned gridT = (unsigned)std::min<long>(ntile, cus);
+#ifdef TL_TIMING
+  // (diagnostic build: EVERY launch of the T kernel writes its clock records - the buffer exists before any of them)
+  const size_t nts = (size_t)cus * 8 * TL_TS_PER_WG;
+  unsigned* ts; CK(hipMalloc(&ts, nts * 4));
+  g.ts = ts;
+  if ((ntile + cus - 1) / cus + 2 > TL_TS_PER_WG / 48) { printf("too many pairs per workgroup for the clock records\n"); return 1; }
+#endif
   printf("rows %ld, D %d, %d CUs, %d launches per variant\n", P, D, cus, reps);
   if (which & 1) {
     const float t = time_ms(st, reps, [&]() { hipLaunchKernelGGL((gemm_tall_kernel<true, true>), dim3(gridT), dim3(512), 0, st, g); });
@@ -112,6 +119,44 @@ int main(int argc, char** argv) {
       printf("G_d = sum_p v_pd c_p c_pT (Gram kernel)   %8.3f ms  %5.1f TFLOP/s algorithmic\n", t, flopsT / t / 1e9);
     }
   }
+#ifdef TL_TIMING
+  if (which & 256) {
+    // per-position clocks of the T kernel (diagnostic build: -DTL_TIMING): mean over workgroups (wave 0) and pairs (the first pair
+    // of a workgroup left out) of the shader clocks from the previous barrier to the position's wait (work) and inside wait + barrier
+    std::vector<unsigned> h(nts);
+    for (int variant = 0; variant < 2; ++variant) {
+      TallArgs n = g; n.ts = ts; if (variant == 1) n.C = nullptr;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipMemset(ts, 0, nts * 4));
+        if (variant == 0) hipLaunchKernelGGL((gemm_tall_kernel<true, true>), dim3(gridT), dim3(512), 0, st, n);
+        else hipLaunchKernelGGL((gemm_tall_kernel<false, false>), dim3(gridT), dim3(512), 0, st, n);
+        CK(hipStreamSynchronize(st));
+      }
+      CK(hipMemcpy(h.data(), ts, nts * 4, hipMemcpyDeviceToHost));
+      for (int wv = 0; wv < 8; wv += 7) {
+        double work[24] = {0}, wait[24] = {0}; long cnt = 0;
+        for (unsigned b = 0; b < gridT; ++b) {
+          const unsigned* q = &h[((size_t)b * 8 + wv) * TL_TS_PER_WG];
+          // record i (position i of the stream of positions): q[2 i] = clock at its wait, q[2 i + 1] = clock behind the barrier of i - 1
+          for (int i = 24; i + 24 < TL_TS_PER_WG / 2 && q[2 * (i + 23)] != 0; i += 24) {
+            for (int p = 0; p < 24; ++p) {
+              work[p] += (double)(unsigned)(q[2 * (i + p)] - q[2 * (i + p) + 1]);
+              wait[p] += (double)(unsigned)(q[2 * (i + p + 1) + 1] - q[2 * (i + p)]);
+            }
+            ++cnt;
+          }
+        }
+        printf("%s, wave %d: %ld pairs; per position: blocks, clocks of work, clocks in wait + barrier\n", variant == 0 ? "T with stores (nt)" : "T row sums only", wv, cnt);
+        double tw = 0, tb = 0;
+        for (int p = 0; p < 24; ++p) {
+          printf("  p %2d  n %d  work %8.0f  wait %7.0f\n", p, tl_nact(p), work[p] / cnt, wait[p] / cnt);
+          tw += work[p] / cnt; tb += wait[p] / cnt;
+        }
+        printf("  pair: work %.0f + wait %.0f = %.0f clocks\n", tw, tb, tw + tb);
+      }
+    }
+  }
+#endif
   if (which & 128) {
     // two-source form (rows from Cb, columns from Ct: one 256 x 256 lower triangle of a rectangular block of a 512 x 512 Gram matrix)
     GemmArgs a{};
