@@ -50,7 +50,8 @@ for name, table, calls in (("fetch", fetch, fcalls), ("write", write, wcalls)):
 
 gemm = [k for k in fetch if "gemm_f64_kernel" in k or "gemm_wide_kernel" in k or "gemm_tall_kernel" in k or "gemm_tallu_kernel" in k or "gemm_gram_kernel" in k or "g_panel_kernel" in k]
 launches = sum(fcalls[k] for k in gemm)
-steps = 3   # bench.py --steps 2 --warmup 1
+# iterations in the traced run = Adam steps (bench.py --steps 2 --warmup 1 runs 1 + 2 iterations and a breakdown pass of 2 more)
+steps = sum(n for k, n in fcalls.items() if "adam_kernel" in k) or 3
 # bench.py's roofline block counts the point contractions only (launches_per_step); the M^3 launches of the small-matrix
 # chain move a few MB each, so the per-launch traffic is quoted over the same launches as `achieved`
 try:
@@ -66,7 +67,7 @@ except Exception:
     commit = "unknown"
 json.dump({
     "commit": commit,
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1, config 2, 1 GPU",
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1 (+ its breakdown pass: 5 iterations in all), config 2, 1 GPU",
     "correction": "FETCH_SIZE (KB) x 1024 x 2 (gfx950 halves wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE (KB) x 1024",
     "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_tallu_kernel + dgp::gemm_gram_kernel + dgp::g_panel_kernel + dgp::gemm_f64_kernel (all instantiations)",
     "launches": launches,
@@ -108,7 +109,7 @@ if mfma_csv:
                         "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / XCDS * SIMDS),
                         "clock_ghz": c["GRBM_GUI_ACTIVE"] / XCDS / dur[d]})
     json.dump({
-        "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace, bench.py --steps 2 --warmup 1, config 2, 1 GPU",
+        "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace, bench.py --steps 2 --warmup 1 (+ its breakdown pass: 5 iterations in all), config 2, 1 GPU",
         "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_tallu_kernel + dgp::gemm_gram_kernel + dgp::g_panel_kernel + dgp::gemm_f64_kernel (all instantiations, all launches of the 3 iterations)",
         "formulas": "executed flops = MOPS_F64 x 512; MfmaUtil = MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs) (rocprofv3's own MfmaUtil expression); clock = GRBM_GUI_ACTIVE/8/duration",
         "executed_mfma_flops_per_step": mops * 512 / steps,
@@ -131,7 +132,7 @@ if lds_csv:
                 tot[row["Counter_Name"]] += float(row["Counter_Value"])
     act, conf, gui = tot["SQ_LDS_IDX_ACTIVE"], tot["SQ_LDS_BANK_CONFLICT"], tot["GRBM_GUI_ACTIVE"]
     json.dump({
-        "source": "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace, bench.py --steps 2 --warmup 1, config 2, 1 GPU",
+        "source": "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace, bench.py --steps 2 --warmup 1 (+ its breakdown pass: 5 iterations in all), config 2, 1 GPU",
         "kernel": "dgp::gemm_wide_kernel + dgp::gemm_tall_kernel + dgp::gemm_tallu_kernel + dgp::gemm_gram_kernel + dgp::g_panel_kernel + dgp::gemm_f64_kernel (all instantiations)",
         "formulas": "bank-conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (cycles the LDS spent re-issuing conflicting lanes over the cycles it was busy); LDS busy = SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE/8 XCDs x 256 CUs) (rocprofv3's LdsUtil expression)",
         "lds_bank_conflict_share": conf / act if act else None,
