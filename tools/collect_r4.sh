@@ -23,7 +23,7 @@ timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --nat-steps 0 > $O/stats_bench.json 2>/dev/null || { echo "stats failed"; exit 1; }
 cd $R
 python tools/summarize_r4.py $O $O/summary || { echo "summarize failed"; exit 1; }
-python tools/iter_timeline.py $(find $O/stats -name '*kernel_trace.csv' | head -1) > $O/summary/r4_iteration_timeline.txt 2>&1 || echo "timeline failed"
+python tools/iter_timeline.py $(find $O/stats -name '*kernel_trace.csv' | head -1) 150 3 > $O/summary/r4_iteration_timeline.txt 2>&1 || echo "timeline failed"
 # the traffic figure must have been measured at the commit under test
 python - <<PY || { echo "traffic json is not from this commit"; exit 1; }
 import json

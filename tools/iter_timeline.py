@@ -1,7 +1,8 @@
 """Timeline of the last training iteration in a rocprofv3 --kernel-trace CSV of bench.py: every launch of at least
 MIN_US microseconds with its start (relative to the previous Adam step), duration, queue and grid, then the busy / idle
 split of the iteration and the total of the shorter launches.
-usage: python tools/iter_timeline.py <kernel_trace.csv> [min_us=150]"""
+usage: python tools/iter_timeline.py <kernel_trace.csv> [min_us=150] [back=0]   (back: the iteration that many before the last one - bench.py's timed
+region lies behind its warm-up and in front of its breakdown pass of min(steps, 10) iterations)"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
@@ -9,7 +10,10 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 adam = [r for r in rows if "adam_kernel" in r["Kernel_Name"]]
 if len(adam) < 2:
     sys.exit("need two Adam steps in the trace")
-ta, tb = int(adam[-2]["Start_Timestamp"]), int(adam[-1]["Start_Timestamp"])
+back = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if len(adam) < back + 2:
+    sys.exit("not that many iterations in the trace")
+ta, tb = int(adam[-2 - back]["Start_Timestamp"]), int(adam[-1 - back]["Start_Timestamp"])
 it = [r for r in rows if ta < int(r["Start_Timestamp"]) <= tb]
 print(f"iteration: {(tb - ta) / 1e6:.3f} ms, {len(it)} launches")
 for r in it:

@@ -117,6 +117,13 @@ int main(int argc, char** argv) {
     else {
       const float t = time_ms(st, reps, [&]() { CK(gemm_f64(st, GEMM_TN, a)); });
       printf("G_d = sum_p v_pd c_p c_pT (Gram kernel)   %8.3f ms  %5.1f TFLOP/s algorithmic\n", t, flopsT / t / 1e9);
+      // the form the training step launches: du_d = sum_p mbar_pd c_p rides on waves 0 and 1
+      double* du = dalloc(256 * D); CK(hipMemset(du, 0, 256 * D * 8));
+      a.gram_mb = mbar; a.gram_du = du;
+      if (gemm_gram_ok(a)) {
+        const float t2 = time_ms(st, reps, [&]() { CK(gemm_f64(st, GEMM_TN, a)); });
+        printf("G_d and du_d = sum_p mbar_pd c_p          %8.3f ms  %5.1f TFLOP/s algorithmic\n", t2, flopsT / t2 / 1e9);
+      }
     }
   }
 #ifdef TL_TIMING
