@@ -4,6 +4,14 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=gpurun_out/r4_power; mkdir -p $O
 sample() { for i in $(seq 1 ${1:-6}); do rocm-smi --showpower --showclocks --showtemp 2>/dev/null | grep -E "Power \(W\)|sclk|Temperature \(Sensor (junction|memory)" | tr -s ' \t' ' ' | tr '\n' ';'; echo; sleep 0.4; done; }
 echo "== idle"; sample 3
+if [ -x tools/mfma_power ]; then
+echo "== MFMA_registers_only (tools/mfma_power 4)"
+timeout -k 10 60 tools/mfma_power 4 > $O/run_mfma.txt 2>&1 &
+pid=$!; sleep 1.5; sample 5; wait $pid; tail -1 $O/run_mfma.txt
+echo "== MFMA_registers_only_20s (tools/mfma_power 20, samples from second 12 on)"
+timeout -k 10 60 tools/mfma_power 20 > $O/run_mfma20.txt 2>&1 &
+pid=$!; sleep 12; sample 8; wait $pid; tail -1 $O/run_mfma20.txt
+fi
 for v in "16 Gram" "4 T_row_sums_only" "1 T_with_stores" "8 dC_tall_tile" "32 g_row_panel"; do
   set -- $v
   echo "== $2 (tools/tall_bench 1000000 400 8 $1)"
