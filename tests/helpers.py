@@ -74,3 +74,31 @@ def split_flat(m, flat):
             off += n
     out[("lik", "variance")] = flat[off]
     return out
+
+
+def collapsed_bound(X, Y, Z, variance, lengthscales, noise, jitter):
+    """Titsias' collapsed bound of sparse GP regression with an ARD squared-exponential kernel and Gaussian noise, and the q(u) that
+    attains it - textbook closed forms, independent of the oracle and of the reference's code:
+        bound = log N(y | 0, Qff + noise I) - tr(Kff - Qff) / (2 noise),   Qff = Kfu (Kuu + jitter I)^-1 Kuf,
+        S* = Kuu (Kuu + Kuf Kfu / noise)^-1 Kuu,   m* = S* Kuu^-1 Kuf y / noise.
+    A one-layer DGP (num_units = []) IS that model (dgp.py:89-100 with the Gaussian variational expectations on the only layer,
+    non-white KL of layers.py:293-300), and ONE natural-gradient step of size 1 from any q(u) lands on (m*, S*): the bound is
+    quadratic in q's natural parameters.  Returns (bound, m* [M, 1], S* [M, M])."""
+    import scipy.linalg as sla
+    ls = np.asarray(lengthscales, dtype=float)
+
+    def k(A, B):
+        A = A / ls
+        B = B / ls
+        d2 = (A * A).sum(1)[:, None] + (B * B).sum(1)[None, :] - 2.0 * A @ B.T
+        return variance * np.exp(-0.5 * np.maximum(d2, 0.0))
+    N, M = X.shape[0], Z.shape[0]
+    L = np.linalg.cholesky(k(Z, Z) + jitter * np.eye(M))
+    A = sla.solve_triangular(L, k(Z, X), lower=True) / np.sqrt(noise)          # [M, N]
+    LB = np.linalg.cholesky(np.eye(M) + A @ A.T)
+    c = sla.solve_triangular(LB, A @ Y, lower=True) / np.sqrt(noise)           # [M, Dy]
+    Dy = Y.shape[1]
+    bound = Dy * (-0.5 * N * np.log(2.0 * np.pi * noise) - np.log(np.diag(LB)).sum()) - 0.5 * (Y * Y).sum() / noise + 0.5 * (c * c).sum()
+    bound += -0.5 * Dy * (N * variance - noise * (A * A).sum()) / noise
+    R = L @ sla.solve_triangular(LB.T, np.eye(M), lower=False)                 # S* = R R^T
+    return float(bound), L @ sla.solve_triangular(LB.T, c, lower=False), R @ R.T

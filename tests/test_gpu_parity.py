@@ -1663,3 +1663,56 @@ def test_cholesky_cotangent_from_the_layer_sums_equals_its_reduction_over_points
         #  largest gradient entry measured with these 256 inducing points; the oracle tests hold both forms to 1e-7)
         assert np.abs(a - b).max() <= 1e-8 * np.abs(b).max(), (white, np.abs(a - b).max(), np.abs(b).max())
         assert np.abs(a - b).max() > 0.0          # (the two forms really are different computations)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# A known answer that involves neither the oracle nor the reference: sparse GP regression's collapsed bound (tests/helpers.py).
+def _one_layer_model(N, D, M, Dy, noise, S, seed=3):
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    import io, contextlib
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, D))
+    Y = np.sin(2 * X[:, :1]) @ np.ones((1, Dy)) + 0.3 * rng.standard_normal((N, Dy))
+    Z = X[rng.permutation(N)[:M]].copy()
+    ls = np.linspace(0.8, 1.2, D)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = DGP(X, Y, Z, [RBF(1.3, ls)], [], Gaussian(variance=noise), num_samples=S)
+    assert len(m.layers) == 1
+    l = m.layers[0]
+    l.q_mu.assign(0.1 * rng.standard_normal(l.q_mu.numpy().shape))            # start away from the prior
+    l.q_sqrt.assign(np.stack([np.tril(0.3 * np.eye(M) + 0.02 * rng.standard_normal((M, M))) for _ in range(Dy)]))
+    return m, X, Y, Z, ls
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(300, 2, 20, 1, 3), (700, 3, 64, 2, 2), (5000, 4, 128, 1, 2), (100_000, 8, 256, 1, 10)],
+                         ids=["N300_M20", "N700_M64_Dy2", "N5000_M128", "config2_N100k_M256"])
+def test_one_natural_gradient_step_of_size_one_reaches_the_collapsed_bound(shape):
+    """dgp_grad_step + dgp_natgrad_step(gamma = 1) on a DGP without hidden layers (= SVGP regression, dgp.py:89-100, 312-322) must land on
+    the optimal q(u), and dgp_elbo there must equal Titsias' collapsed bound - closed forms from the textbook, no oracle involved.
+    The last case is BASELINE config 2's N, D, M, S: 100 000 rows through the production kernels (solve, T, dC, Gram, row-panel g)."""
+    from helpers import collapsed_bound
+    N, D, M, Dy, S = shape
+    noise = 0.37
+    m, X, Y, Z, ls = _one_layer_model(N, D, M, Dy, noise, S)
+    e0 = m.ELBO()
+    mask = m._natgrad_setup(True)
+    c = m._grad_step(m.data)
+    c.natgrad_step(1.0, mask)
+    m._device_newer = True
+    e1 = m.ELBO()
+    bound, m_opt, S_opt = collapsed_bound(X, Y, Z, 1.3, ls, noise, 1e-6)
+    assert e0 < e1 - 1.0
+    assert abs(e1 - bound) < 1e-9 * abs(bound), (e1, bound)
+    l = m.layers[0]
+    scale = max(1.0, np.abs(m_opt).max())
+    assert np.abs(l.q_mu.numpy() - m_opt).max() < 1e-8 * scale
+    for d in range(Dy):
+        Ld = np.tril(l.q_sqrt.numpy()[d])
+        assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-8 * max(1.0, np.abs(S_opt).max())
+    # a second step of size one stays put (idempotence at the optimum)
+    c = m._grad_step(m.data)
+    c.natgrad_step(1.0, mask)
+    m._device_newer = True
+    assert abs(m.ELBO() - bound) < 1e-9 * abs(bound)

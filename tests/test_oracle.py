@@ -351,3 +351,37 @@ def test_graph_replay_tolerance_is_amplified_summation_order_noise(natgrad):
     assert 3e9 < amp < 3e10, spread                                   # measured 1.07e10
     assert 5.0 < spread[1e-15] / spread[1e-16] < 20.0, spread        # linear
     assert 0.3e-6 < amp * 1.1e-16 < 3e-6                              # the GPU test's 1e-6 = one rounding unit of the largest entry
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# A known answer that needs neither the reference nor the autograd twin: sparse GP regression's collapsed bound.
+@pytest.mark.parametrize("shape", [(300, 2, 20, 1), (500, 3, 40, 2)])
+def test_one_natural_gradient_step_of_size_one_reaches_the_collapsed_bound(shape):
+    """A DGP without hidden layers is SVGP regression; with a Gaussian likelihood its ELBO is quadratic in q(u)'s natural parameters,
+    so NaturalGradient(gamma=1).minimize lands on the optimal q(u) in one step (dgp.py:312-322,343 with gamma = 1), where the ELBO
+    equals Titsias' collapsed bound.  Pins the oracle's natural-gradient step, its non-white KL at q != prior, the conditional and the
+    Gaussian variational expectations against closed forms written from the textbook (tests/helpers.py::collapsed_bound)."""
+    from dgp_oracle_train import OracleTrainer
+    from helpers import collapsed_bound
+    N, D, M, Dy = shape
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((N, D))
+    Y = np.sin(2 * X[:, :1]) @ np.ones((1, Dy)) + 0.3 * rng.standard_normal((N, Dy))
+    Z = X[:M].copy()
+    ls = np.linspace(0.8, 1.2, D)
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(1.3, ls)], [], lik_variance=0.37, num_samples=3)
+    assert len(mo.layers) == 1
+    l = mo.layers[0]
+    l.q_mu = 0.1 * rng.standard_normal(l.q_mu.shape)                  # start away from the prior
+    l.q_sqrt = np.stack([np.tril(0.3 * np.eye(M) + 0.02 * rng.standard_normal((M, M))) for _ in range(Dy)])
+    tr = OracleTrainer(mo, base_seed=5)
+    e0, _ = tr._grads(tr._next_zs())
+    tr.natgrad_iteration(1.0, [0])
+    e1, _ = tr._grads(tr._next_zs())
+    bound, m_opt, S_opt = collapsed_bound(X, Y, Z, 1.3, ls, 0.37, O.JITTER)
+    assert e0 < e1 - 1.0
+    assert abs(e1 - bound) < 1e-9 * abs(bound), (e1, bound)
+    assert np.abs(l.q_mu - m_opt).max() < 1e-9
+    for d in range(Dy):
+        Ld = np.tril(l.q_sqrt[d])
+        assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-9
