@@ -1716,3 +1716,48 @@ def test_one_natural_gradient_step_of_size_one_reaches_the_collapsed_bound(shape
     c.natgrad_step(1.0, mask)
     m._device_newer = True
     assert abs(m.ELBO() - bound) < 1e-9 * abs(bound)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(700, 3, 64, 1, 2), (5000, 4, 128, 1, 2), (40_000, 8, 256, 1, 3)], ids=["N700_M64", "N5000_M128", "N40000_M256"])
+def test_hyperparameter_gradients_at_the_optimal_q_are_those_of_the_collapsed_bound(shape):
+    """Envelope theorem: at the q(u) that maximises the ELBO, d ELBO / d(kernel variance, lengthscales, noise variance, Z) equals the
+    derivative of the collapsed bound - which is differentiated HERE by central differences of the textbook closed form
+    (tests/helpers.py::collapsed_bound), no oracle and no autograd involved.  Pins the hand-written backward pass through the kernel
+    (dK -> g -> g [Z|1], the Kuu chain, Q') and the likelihood's own gradient; d ELBO / d q(u) must vanish there."""
+    from helpers import collapsed_bound
+    N, D, M, Dy, S = shape
+    noise, var = 0.37, 1.3
+    m, X, Y, Z, ls = _one_layer_model(N, D, M, Dy, noise, S)
+    mask = m._natgrad_setup(True)
+    c = m._grad_step(m.data)
+    c.natgrad_step(1.0, mask)
+    m._device_newer = True
+    c = m._grad_step(m.data)
+    G = split_flat(m, c.grad_get())
+    bound = collapsed_bound(X, Y, Z, var, ls, noise, 1e-6)[0]
+    assert abs(c.last_elbo() - bound) < 1e-9 * abs(bound)
+
+    def fd(f, h):
+        return (f(+h) - f(-h)) / (2.0 * h)
+    h = 1e-4
+    want = {("var",): fd(lambda e: collapsed_bound(X, Y, Z, var + e, ls, noise, 1e-6)[0], h),
+            ("noise",): fd(lambda e: collapsed_bound(X, Y, Z, var, ls, noise + e, 1e-6)[0], h)}
+    for j in range(D):
+        ej = np.zeros(D); ej[j] = 1.0
+        want[("ls", j)] = fd(lambda e: collapsed_bound(X, Y, Z, var, ls + e * ej, noise, 1e-6)[0], h)
+    got = {("var",): float(G[(0, "variance")]), ("noise",): float(G[("lik", "variance")])}
+    for j in range(D):
+        got[("ls", j)] = float(np.ravel(G[(0, "lengthscales")])[j])
+    rng = np.random.default_rng(11)
+    for t in range(2):                                   # two random directions in Z
+        V = rng.standard_normal(Z.shape)
+        V /= np.linalg.norm(V)
+        want[("Z", t)] = fd(lambda e: collapsed_bound(X, Y, Z + e * V, var, ls, noise, 1e-6)[0], h)
+        got[("Z", t)] = float((G[(0, "Z")] * V).sum())
+    scale = max(abs(v) for v in want.values())
+    for k in want:
+        assert abs(got[k] - want[k]) < 2e-6 * scale, (k, got[k], want[k], scale)
+    # the optimum is stationary in q(u)
+    assert np.abs(G[(0, "q_mu")]).max() < 1e-6 * scale
+    assert np.abs(np.tril(G[(0, "q_sqrt")])).max() < 1e-6 * scale

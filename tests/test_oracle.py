@@ -385,3 +385,38 @@ def test_one_natural_gradient_step_of_size_one_reaches_the_collapsed_bound(shape
     for d in range(Dy):
         Ld = np.tril(l.q_sqrt[d])
         assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-9
+
+
+def test_oracle_hyperparameter_gradients_at_the_optimal_q_are_those_of_the_collapsed_bound():
+    """Envelope theorem (see the GPU test of the same name in test_gpu_parity.py): at the optimal q(u) the autograd twin's
+    d ELBO / d(variance, lengthscales, noise, Z) must equal central differences of the textbook bound, and d ELBO / d q(u) must vanish."""
+    from dgp_oracle_train import OracleTrainer
+    from helpers import collapsed_bound
+    N, D, M = 300, 2, 20
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((N, D))
+    Y = np.sin(2 * X[:, :1]) + 0.3 * rng.standard_normal((N, 1))
+    Z = X[:M].copy()
+    ls = np.array([0.8, 1.2])
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(1.3, ls)], [], lik_variance=0.37, num_samples=2)
+    tr = OracleTrainer(mo, base_seed=5)
+    tr.natgrad_iteration(1.0, [0])
+    _, G = tr._grads(tr._next_zs())
+    h = 1e-4
+
+    def fd(f):
+        return (f(+h) - f(-h)) / (2.0 * h)
+    want = {"variance": fd(lambda e: collapsed_bound(X, Y, Z, 1.3 + e, ls, 0.37, O.JITTER)[0]),
+            "noise": fd(lambda e: collapsed_bound(X, Y, Z, 1.3, ls, 0.37 + e, O.JITTER)[0]),
+            "ls0": fd(lambda e: collapsed_bound(X, Y, Z, 1.3, ls + e * np.array([1.0, 0.0]), 0.37, O.JITTER)[0]),
+            "ls1": fd(lambda e: collapsed_bound(X, Y, Z, 1.3, ls + e * np.array([0.0, 1.0]), 0.37, O.JITTER)[0])}
+    V = rng.standard_normal(Z.shape)
+    V /= np.linalg.norm(V)
+    want["Z"] = fd(lambda e: collapsed_bound(X, Y, Z + e * V, 1.3, ls, 0.37, O.JITTER)[0])
+    got = {"variance": float(G[(0, "variance")]), "noise": float(G[("lik", "variance")]),
+           "ls0": float(np.ravel(G[(0, "lengthscales")])[0]), "ls1": float(np.ravel(G[(0, "lengthscales")])[1]),
+           "Z": float((np.asarray(G[(0, "Z")]) * V).sum())}
+    scale = max(abs(v) for v in want.values())
+    for k in want:
+        assert abs(got[k] - want[k]) < 2e-6 * scale, (k, got[k], want[k])
+    assert np.abs(G[(0, "q_mu")]).max() < 1e-6 * scale and np.abs(np.tril(np.asarray(G[(0, "q_sqrt")])[0])).max() < 1e-6 * scale
