@@ -102,3 +102,25 @@ def collapsed_bound(X, Y, Z, variance, lengthscales, noise, jitter):
     bound += -0.5 * Dy * (N * variance - noise * (A * A).sum()) / noise
     R = L @ sla.solve_triangular(LB.T, np.eye(M), lower=False)                 # S* = R R^T
     return float(bound), L @ sla.solve_triangular(LB.T, c, lower=False), R @ R.T
+
+
+def sparse_gp_predict(X, Y, Z, Xnew, variance, lengthscales, noise, jitter):
+    """Predictive mean and variance of f at Xnew under the optimal q(u) of sparse GP regression (Titsias 2009, eq. 6):
+        mean = K*u Sigma Kuf y / noise,  var = k** - K*u Kuu^-1 Ku* + K*u Sigma Ku*,  Sigma = (Kuu + Kuf Kfu / noise)^-1.
+    Textbook closed form (same kernel and jitter convention as collapsed_bound)."""
+    import scipy.linalg as sla
+    ls = np.asarray(lengthscales, dtype=float)
+
+    def k(A, B):
+        A = A / ls
+        B = B / ls
+        d2 = (A * A).sum(1)[:, None] + (B * B).sum(1)[None, :] - 2.0 * A @ B.T
+        return variance * np.exp(-0.5 * np.maximum(d2, 0.0))
+    M = Z.shape[0]
+    L = np.linalg.cholesky(k(Z, Z) + jitter * np.eye(M))
+    A = sla.solve_triangular(L, k(Z, X), lower=True) / np.sqrt(noise)
+    LB = np.linalg.cholesky(np.eye(M) + A @ A.T)
+    c = sla.solve_triangular(LB, A @ Y, lower=True) / np.sqrt(noise)
+    As = sla.solve_triangular(L, k(Z, Xnew), lower=True)                  # L^-1 Ku*
+    Bs = sla.solve_triangular(LB, As, lower=True)                         # LB^-1 L^-1 Ku*
+    return Bs.T @ c, (variance - (As * As).sum(0) + (Bs * Bs).sum(0))[:, None] * np.ones((1, Y.shape[1]))

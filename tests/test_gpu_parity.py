@@ -1711,6 +1711,18 @@ def test_one_natural_gradient_step_of_size_one_reaches_the_collapsed_bound(shape
     for d in range(Dy):
         Ld = np.tril(l.q_sqrt.numpy()[d])
         assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-8 * max(1.0, np.abs(S_opt).max())
+    # predictions under that q(u): Titsias' predictive equations (predict_f per sample, predict_y, the moment-matched predict)
+    from helpers import sparse_gp_predict
+    Xnew = np.random.default_rng(5).standard_normal((57, D))
+    pm, pv = sparse_gp_predict(X, Y, Z, Xnew, 1.3, ls, noise, 1e-6)
+    Fm, Fv = m.predict_f(Xnew, S=4)
+    Fm, Fv = np.asarray(Fm), np.asarray(Fv)
+    assert Fm.shape == (4, 57, Dy)
+    assert np.abs(Fm - pm[None]).max() < 1e-8 * max(1.0, np.abs(pm).max()) and np.abs(Fv - pv[None]).max() < 1e-8
+    ym, yv = m.predict_y(Xnew, 3)
+    assert np.abs(np.asarray(ym) - pm[None]).max() < 1e-8 * max(1.0, np.abs(pm).max()) and np.abs(np.asarray(yv) - (pv + noise)[None]).max() < 1e-8
+    mean, var = m.predict(Xnew, 5)
+    assert np.abs(mean - pm).max() < 1e-8 * max(1.0, np.abs(pm).max()) and np.abs(var - (pv + noise)).max() < 1e-8
     # a second step of size one stays put (idempotence at the optimum)
     c = m._grad_step(m.data)
     c.natgrad_step(1.0, mask)
