@@ -1667,7 +1667,7 @@ def test_cholesky_cotangent_from_the_layer_sums_equals_its_reduction_over_points
 
 # ---------------------------------------------------------------------------------------------------------------
 # A known answer that involves neither the oracle nor the reference: sparse GP regression's collapsed bound (tests/helpers.py).
-def _one_layer_model(N, D, M, Dy, noise, S, seed=3):
+def _one_layer_model(N, D, M, Dy, noise, S, seed=3, white=False):
     from dgp_dace.gpflow_compat import RBF, Gaussian
     from dgp_dace.models.dgp import DGP
     import io, contextlib
@@ -1677,7 +1677,7 @@ def _one_layer_model(N, D, M, Dy, noise, S, seed=3):
     Z = X[rng.permutation(N)[:M]].copy()
     ls = np.linspace(0.8, 1.2, D)
     with contextlib.redirect_stdout(io.StringIO()):
-        m = DGP(X, Y, Z, [RBF(1.3, ls)], [], Gaussian(variance=noise), num_samples=S)
+        m = DGP(X, Y, Z, [RBF(1.3, ls)], [], Gaussian(variance=noise), white=white, num_samples=S)
     assert len(m.layers) == 1
     l = m.layers[0]
     l.q_mu.assign(0.1 * rng.standard_normal(l.q_mu.numpy().shape))            # start away from the prior
@@ -1686,16 +1686,18 @@ def _one_layer_model(N, D, M, Dy, noise, S, seed=3):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(300, 2, 20, 1, 3), (700, 3, 64, 2, 2), (5000, 4, 128, 1, 2), (100_000, 8, 256, 1, 10)],
-                         ids=["N300_M20", "N700_M64_Dy2", "N5000_M128", "config2_N100k_M256"])
+@pytest.mark.parametrize("shape", [(300, 2, 20, 1, 3), (700, 3, 64, 2, 2), (5000, 4, 128, 1, 2), (100_000, 8, 256, 1, 10),
+                                   (300, 2, 20, 1, 3, True), (700, 3, 64, 2, 2, True), (20_000, 8, 256, 1, 2, True)],
+                         ids=["N300_M20", "N700_M64_Dy2", "N5000_M128", "config2_N100k_M256", "white_N300_M20", "white_N700_M64_Dy2", "white_N20000_M256"])
 def test_one_natural_gradient_step_of_size_one_reaches_the_collapsed_bound(shape):
     """dgp_grad_step + dgp_natgrad_step(gamma = 1) on a DGP without hidden layers (= SVGP regression, dgp.py:89-100, 312-322) must land on
     the optimal q(u), and dgp_elbo there must equal Titsias' collapsed bound - closed forms from the textbook, no oracle involved.
     The last case is BASELINE config 2's N, D, M, S: 100 000 rows through the production kernels (solve, T, dC, Gram, row-panel g)."""
     from helpers import collapsed_bound
-    N, D, M, Dy, S = shape
+    N, D, M, Dy, S = shape[:5]
+    white = len(shape) > 5 and shape[5]            # q over v = Lu^-1 u (layers.py:238-241): compared in u's coordinates below
     noise = 0.37
-    m, X, Y, Z, ls = _one_layer_model(N, D, M, Dy, noise, S)
+    m, X, Y, Z, ls = _one_layer_model(N, D, M, Dy, noise, S, white=white)
     e0 = m.ELBO()
     mask = m._natgrad_setup(True)
     c = m._grad_step(m.data)
@@ -1707,9 +1709,14 @@ def test_one_natural_gradient_step_of_size_one_reaches_the_collapsed_bound(shape
     assert abs(e1 - bound) < 1e-9 * abs(bound), (e1, bound)
     l = m.layers[0]
     scale = max(1.0, np.abs(m_opt).max())
-    assert np.abs(l.q_mu.numpy() - m_opt).max() < 1e-8 * scale
+    Lu = np.eye(M)
+    if white:
+        Zs = Z / ls
+        d2 = (Zs * Zs).sum(1)[:, None] + (Zs * Zs).sum(1)[None, :] - 2.0 * Zs @ Zs.T
+        Lu = np.linalg.cholesky(1.3 * np.exp(-0.5 * np.maximum(d2, 0.0)) + 1e-6 * np.eye(M))
+    assert np.abs(Lu @ l.q_mu.numpy() - m_opt).max() < 1e-8 * scale
     for d in range(Dy):
-        Ld = np.tril(l.q_sqrt.numpy()[d])
+        Ld = Lu @ np.tril(l.q_sqrt.numpy()[d])
         assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-8 * max(1.0, np.abs(S_opt).max())
     # predictions under that q(u): Titsias' predictive equations (predict_f per sample, predict_y, the moment-matched predict)
     from helpers import sparse_gp_predict

@@ -355,8 +355,9 @@ def test_graph_replay_tolerance_is_amplified_summation_order_noise(natgrad):
 
 # ---------------------------------------------------------------------------------------------------------------
 # A known answer that needs neither the reference nor the autograd twin: sparse GP regression's collapsed bound.
+@pytest.mark.parametrize("white", [False, True])
 @pytest.mark.parametrize("shape", [(300, 2, 20, 1), (500, 3, 40, 2)])
-def test_one_natural_gradient_step_of_size_one_reaches_the_collapsed_bound(shape):
+def test_one_natural_gradient_step_of_size_one_reaches_the_collapsed_bound(shape, white):
     """A DGP without hidden layers is SVGP regression; with a Gaussian likelihood its ELBO is quadratic in q(u)'s natural parameters,
     so NaturalGradient(gamma=1).minimize lands on the optimal q(u) in one step (dgp.py:312-322,343 with gamma = 1), where the ELBO
     equals Titsias' collapsed bound.  Pins the oracle's natural-gradient step, its non-white KL at q != prior, the conditional and the
@@ -369,7 +370,7 @@ def test_one_natural_gradient_step_of_size_one_reaches_the_collapsed_bound(shape
     Y = np.sin(2 * X[:, :1]) @ np.ones((1, Dy)) + 0.3 * rng.standard_normal((N, Dy))
     Z = X[:M].copy()
     ls = np.linspace(0.8, 1.2, D)
-    mo = O.OracleDGP(X, Y, Z, [O.RBF(1.3, ls)], [], lik_variance=0.37, num_samples=3)
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(1.3, ls)], [], lik_variance=0.37, white=white, num_samples=3)
     assert len(mo.layers) == 1
     l = mo.layers[0]
     l.q_mu = 0.1 * rng.standard_normal(l.q_mu.shape)                  # start away from the prior
@@ -381,9 +382,11 @@ def test_one_natural_gradient_step_of_size_one_reaches_the_collapsed_bound(shape
     bound, m_opt, S_opt = collapsed_bound(X, Y, Z, 1.3, ls, 0.37, O.JITTER)
     assert e0 < e1 - 1.0
     assert abs(e1 - bound) < 1e-9 * abs(bound), (e1, bound)
-    assert np.abs(l.q_mu - m_opt).max() < 1e-9
+    # (white=True: q is over v = Lu^-1 u, layers.py:238-241 - compare in u's coordinates)
+    Lu = np.linalg.cholesky(O.RBF(1.3, ls).K(Z) + O.JITTER * np.eye(M)) if white else np.eye(M)
+    assert np.abs(Lu @ l.q_mu - m_opt).max() < 1e-9
     for d in range(Dy):
-        Ld = np.tril(l.q_sqrt[d])
+        Ld = Lu @ np.tril(l.q_sqrt[d])
         assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-9
 
 
