@@ -76,8 +76,25 @@ def split_flat(m, flat):
     return out
 
 
-def collapsed_bound(X, Y, Z, variance, lengthscales, noise, jitter):
-    """Titsias' collapsed bound of sparse GP regression with an ARD squared-exponential kernel and Gaussian noise, and the q(u) that
+def stationary_kernel(A, B, variance, lengthscales, kind="rbf"):
+    """k(a, b) for the ARD squared-exponential, Matern-3/2 and Matern-5/2 kernels, from their published formulas
+    (Rasmussen & Williams eq. 4.9, 4.17); r is clamped away from 0 as gpflow does (r^2 >= 1e-36)."""
+    ls = np.asarray(lengthscales, dtype=float)
+    A = A / ls
+    B = B / ls
+    d2 = np.maximum((A * A).sum(1)[:, None] + (B * B).sum(1)[None, :] - 2.0 * A @ B.T, 0.0)
+    if kind == "rbf":
+        return variance * np.exp(-0.5 * d2)
+    r = np.sqrt(np.maximum(d2, 1e-36))
+    if kind == "matern32":
+        return variance * (1.0 + np.sqrt(3.0) * r) * np.exp(-np.sqrt(3.0) * r)
+    if kind == "matern52":
+        return variance * (1.0 + np.sqrt(5.0) * r + 5.0 / 3.0 * d2) * np.exp(-np.sqrt(5.0) * r)
+    raise ValueError(kind)
+
+
+def collapsed_bound(X, Y, Z, variance, lengthscales, noise, jitter, kind="rbf"):
+    """Titsias' collapsed bound of sparse GP regression with a stationary ARD kernel (`kind`) and Gaussian noise, and the q(u) that
     attains it - textbook closed forms, independent of the oracle and of the reference's code:
         bound = log N(y | 0, Qff + noise I) - tr(Kff - Qff) / (2 noise),   Qff = Kfu (Kuu + jitter I)^-1 Kuf,
         S* = Kuu (Kuu + Kuf Kfu / noise)^-1 Kuu,   m* = S* Kuu^-1 Kuf y / noise.
@@ -85,13 +102,8 @@ def collapsed_bound(X, Y, Z, variance, lengthscales, noise, jitter):
     non-white KL of layers.py:293-300), and ONE natural-gradient step of size 1 from any q(u) lands on (m*, S*): the bound is
     quadratic in q's natural parameters.  Returns (bound, m* [M, 1], S* [M, M])."""
     import scipy.linalg as sla
-    ls = np.asarray(lengthscales, dtype=float)
-
     def k(A, B):
-        A = A / ls
-        B = B / ls
-        d2 = (A * A).sum(1)[:, None] + (B * B).sum(1)[None, :] - 2.0 * A @ B.T
-        return variance * np.exp(-0.5 * np.maximum(d2, 0.0))
+        return stationary_kernel(A, B, variance, lengthscales, kind)
     N, M = X.shape[0], Z.shape[0]
     L = np.linalg.cholesky(k(Z, Z) + jitter * np.eye(M))
     A = sla.solve_triangular(L, k(Z, X), lower=True) / np.sqrt(noise)          # [M, N]
@@ -104,18 +116,13 @@ def collapsed_bound(X, Y, Z, variance, lengthscales, noise, jitter):
     return float(bound), L @ sla.solve_triangular(LB.T, c, lower=False), R @ R.T
 
 
-def sparse_gp_predict(X, Y, Z, Xnew, variance, lengthscales, noise, jitter):
+def sparse_gp_predict(X, Y, Z, Xnew, variance, lengthscales, noise, jitter, kind="rbf"):
     """Predictive mean and variance of f at Xnew under the optimal q(u) of sparse GP regression (Titsias 2009, eq. 6):
         mean = K*u Sigma Kuf y / noise,  var = k** - K*u Kuu^-1 Ku* + K*u Sigma Ku*,  Sigma = (Kuu + Kuf Kfu / noise)^-1.
     Textbook closed form (same kernel and jitter convention as collapsed_bound)."""
     import scipy.linalg as sla
-    ls = np.asarray(lengthscales, dtype=float)
-
     def k(A, B):
-        A = A / ls
-        B = B / ls
-        d2 = (A * A).sum(1)[:, None] + (B * B).sum(1)[None, :] - 2.0 * A @ B.T
-        return variance * np.exp(-0.5 * np.maximum(d2, 0.0))
+        return stationary_kernel(A, B, variance, lengthscales, kind)
     M = Z.shape[0]
     L = np.linalg.cholesky(k(Z, Z) + jitter * np.eye(M))
     A = sla.solve_triangular(L, k(Z, X), lower=True) / np.sqrt(noise)

@@ -1667,8 +1667,8 @@ def test_cholesky_cotangent_from_the_layer_sums_equals_its_reduction_over_points
 
 # ---------------------------------------------------------------------------------------------------------------
 # A known answer that involves neither the oracle nor the reference: sparse GP regression's collapsed bound (tests/helpers.py).
-def _one_layer_model(N, D, M, Dy, noise, S, seed=3, white=False):
-    from dgp_dace.gpflow_compat import RBF, Gaussian
+def _one_layer_model(N, D, M, Dy, noise, S, seed=3, white=False, kind="rbf"):
+    from dgp_dace.gpflow_compat import RBF, Matern32, Matern52, Gaussian
     from dgp_dace.models.dgp import DGP
     import io, contextlib
     rng = np.random.default_rng(seed)
@@ -1677,7 +1677,8 @@ def _one_layer_model(N, D, M, Dy, noise, S, seed=3, white=False):
     Z = X[rng.permutation(N)[:M]].copy()
     ls = np.linspace(0.8, 1.2, D)
     with contextlib.redirect_stdout(io.StringIO()):
-        m = DGP(X, Y, Z, [RBF(1.3, ls)], [], Gaussian(variance=noise), white=white, num_samples=S)
+        kern = {"rbf": RBF, "matern32": Matern32, "matern52": Matern52}[kind](1.3, ls)
+        m = DGP(X, Y, Z, [kern], [], Gaussian(variance=noise), white=white, num_samples=S)
     assert len(m.layers) == 1
     l = m.layers[0]
     l.q_mu.assign(0.1 * rng.standard_normal(l.q_mu.numpy().shape))            # start away from the prior
@@ -1780,3 +1781,47 @@ def test_hyperparameter_gradients_at_the_optimal_q_are_those_of_the_collapsed_bo
     # the optimum is stationary in q(u)
     assert np.abs(G[(0, "q_mu")]).max() < 1e-6 * scale
     assert np.abs(np.tril(G[(0, "q_sqrt")])).max() < 1e-6 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["matern32", "matern52"])
+@pytest.mark.parametrize("shape", [(700, 3, 64, 1, 2), (20_000, 8, 256, 1, 2)], ids=["N700_M64", "N20000_M256"])
+def test_matern_layers_against_the_collapsed_bound(shape, kind):
+    """The same closed forms with the Matern-3/2 and -5/2 kernels written from their published formulas (SO_BO.py:194-197,
+    241-244): ELBO and q(u) after one natural-gradient step of size one, the predictive equations, and the hyper-parameter gradients
+    against central differences of the bound."""
+    from helpers import collapsed_bound, sparse_gp_predict
+    N, D, M, Dy, S = shape
+    noise, var = 0.37, 1.3
+    m, X, Y, Z, ls = _one_layer_model(N, D, M, Dy, noise, S, kind=kind)
+    mask = m._natgrad_setup(True)
+    c = m._grad_step(m.data)
+    c.natgrad_step(1.0, mask)
+    m._device_newer = True
+    bound, m_opt, S_opt = collapsed_bound(X, Y, Z, var, ls, noise, 1e-6, kind)
+    assert abs(m.ELBO() - bound) < 1e-9 * abs(bound)
+    l = m.layers[0]
+    assert np.abs(l.q_mu.numpy() - m_opt).max() < 1e-8 * max(1.0, np.abs(m_opt).max())
+    Ld = np.tril(l.q_sqrt.numpy()[0])
+    assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-8 * max(1.0, np.abs(S_opt).max())
+    Xnew = np.random.default_rng(5).standard_normal((57, D))
+    pm, pv = sparse_gp_predict(X, Y, Z, Xnew, var, ls, noise, 1e-6, kind)
+    Fm, Fv = m.predict_f(Xnew, S=2)
+    assert np.abs(np.asarray(Fm) - pm[None]).max() < 1e-8 * max(1.0, np.abs(pm).max()) and np.abs(np.asarray(Fv) - pv[None]).max() < 1e-8
+    c = m._grad_step(m.data)
+    G = split_flat(m, c.grad_get())
+    h = 1e-4
+
+    def fd(f):
+        return (f(+h) - f(-h)) / (2.0 * h)
+    want = {"var": fd(lambda e: collapsed_bound(X, Y, Z, var + e, ls, noise, 1e-6, kind)[0]),
+            "noise": fd(lambda e: collapsed_bound(X, Y, Z, var, ls, noise + e, 1e-6, kind)[0]),
+            "ls0": fd(lambda e: collapsed_bound(X, Y, Z, var, ls + e * np.eye(D)[0], noise, 1e-6, kind)[0])}
+    V = np.random.default_rng(11).standard_normal(Z.shape)
+    V /= np.linalg.norm(V)
+    want["Z"] = fd(lambda e: collapsed_bound(X, Y, Z + e * V, var, ls, noise, 1e-6, kind)[0])
+    got = {"var": float(G[(0, "variance")]), "noise": float(G[("lik", "variance")]), "ls0": float(np.ravel(G[(0, "lengthscales")])[0]),
+           "Z": float((G[(0, "Z")] * V).sum())}
+    scale = max(abs(v) for v in want.values())
+    for k in want:
+        assert abs(got[k] - want[k]) < 2e-6 * scale, (kind, k, got[k], want[k], scale)
