@@ -1825,3 +1825,57 @@ def test_matern_layers_against_the_collapsed_bound(shape, kind):
     scale = max(abs(v) for v in want.values())
     for k in want:
         assert abs(got[k] - want[k]) < 2e-6 * scale, (kind, k, got[k], want[k], scale)
+
+
+DIST_COLLAPSED_WORKER = r'''
+import os, sys, io, contextlib
+sys.path[:0] = [os.path.join(ROOT, "dgp-toolbox_amd"), os.path.join(ROOT, "tests")]
+os.environ["LOCAL_RANK"] = str(RANK)
+import numpy as np, torch, torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % PORT, rank=RANK, world_size=2)
+from dgp_dace.gpflow_compat import RBF, Gaussian
+from dgp_dace.models.dgp import DGP
+rng = np.random.default_rng(3)
+N, D, M = 30_011, 4, 256                          # an odd N: the two shards differ in size
+X = rng.standard_normal((N, D)); Y = np.sin(2 * X[:, :1]) + 0.3 * rng.standard_normal((N, 1))
+Z = X[rng.permutation(N)[:M]].copy()
+ls = np.linspace(0.8, 1.2, D)
+with contextlib.redirect_stdout(io.StringIO()):
+    m = DGP(X, Y, Z, [RBF(1.3, ls)], [], Gaussian(variance=0.37), num_samples=2)
+assert m._engine() is not None and m._dist is not None and m._dist.world == 2
+mask = m._natgrad_setup(True)
+c = m._grad_step(m.data)                          # shard -> partial sums -> all-reduce of the transport buffer -> finish
+c.natgrad_step(1.0, mask)
+m._device_newer = True
+c = m._grad_step(m.data)
+if RANK == 0:
+    np.savez(OUT, elbo=c.last_elbo(), e2=m.ELBO(), q_mu=m.layers[0].q_mu.numpy(), q_sqrt=m.layers[0].q_sqrt.numpy(), X=X, Y=Y, Z=Z, ls=ls)
+else:
+    m.ELBO()
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_two_ranks_reach_the_collapsed_bound(tmp_path):
+    """The sharded path (two ranks on this GPU over gloo: uneven shards, transport form of the partial sums, replicated chain + natural
+    gradient) against the textbook closed form: after one step of size one both ranks sit on the optimal q(u) and the all-reduced
+    ELBO is the collapsed bound of the WHOLE data set."""
+    import subprocess, sys, os
+    from helpers import collapsed_bound
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 31600 + (os.getpid() % 2000)
+    out = str(tmp_path / "dist_collapsed.npz")
+    procs = []
+    for rank in (0, 1):
+        code = f"ROOT={root!r}\nPORT={port}\nRANK={rank}\nOUT={out!r}\n" + DIST_COLLAPSED_WORKER
+        procs.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    d = np.load(out)
+    bound, m_opt, S_opt = collapsed_bound(d["X"], d["Y"], d["Z"], 1.3, d["ls"], 0.37, 1e-6)
+    assert abs(d["elbo"] - bound) < 1e-9 * abs(bound) and abs(d["e2"] - bound) < 1e-9 * abs(bound)
+    assert np.abs(d["q_mu"] - m_opt).max() < 1e-8 * max(1.0, np.abs(m_opt).max())
+    Ld = np.tril(d["q_sqrt"][0])
+    assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-8 * max(1.0, np.abs(S_opt).max())
