@@ -1879,3 +1879,45 @@ def test_two_ranks_reach_the_collapsed_bound(tmp_path):
     assert np.abs(d["q_mu"] - m_opt).max() < 1e-8 * max(1.0, np.abs(m_opt).max())
     Ld = np.tril(d["q_sqrt"][0])
     assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-8 * max(1.0, np.abs(S_opt).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2000, 3, 64, 3), (30_000, 8, 256, 2)], ids=["N2000_M64", "N30000_M256"])
+def test_two_layer_model_with_a_silent_hidden_layer_against_the_collapsed_bound(shape):
+    """The layer-to-layer plumbing against a closed form: hidden layer at the prior (q_mu = 0: its mean is the identity mean function,
+    KL = 0) and ZERO normals, so that every sample's hidden output is X itself; the output layer is then SVGP regression on X with ITS
+    kernel and inducing inputs.  One natural-gradient step of size one on the output layer alone (layer_mask [0, 1]) must reach the
+    collapsed bound of that regression (dgp.py:34-100 with zs given, layers.py:87-130 at z = 0)."""
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    from helpers import collapsed_bound
+    import io, contextlib
+    N, D, M, S = shape
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((N, D))
+    Y = np.sin(2 * X[:, :1]) + 0.3 * rng.standard_normal((N, 1))
+    Z = X[rng.permutation(N)[:M]].copy()
+    ls2 = np.linspace(0.9, 1.4, D)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = DGP(X, Y, Z, [RBF(0.7, np.ones(D)), RBF(1.1, ls2)], [D], Gaussian(variance=0.25), num_samples=S)
+    assert len(m.layers) == 2 and m.layers[0].mean_function.kind == "identity"
+    Z2 = m.layers[1].feature.Z.numpy()
+    assert np.abs(Z2 - Z).max() == 0.0                     # (identity mean: the inducing inputs pass through unchanged, layer_initializations)
+    ctx = m._sync_model()
+    m._sync_data(m.data)
+    zs = [np.zeros((S, N, D)), np.zeros((S, N, 1))]
+    ctx.grad_partial(S, 1, zs)
+    ctx.grad_finish()
+    ctx.natgrad_step(1.0, [False, True])
+    m._device_newer = True
+    data, kl = ctx.elbo(S, 2, zs)
+    bound, m_opt, S_opt = collapsed_bound(X, Y, Z, 1.1, ls2, 0.25, 1e-6)
+    assert abs((data - kl) - bound) < 1e-9 * abs(bound), (data - kl, bound)
+    l = m.layers[1]
+    assert np.abs(l.q_mu.numpy() - m_opt).max() < 1e-8 * max(1.0, np.abs(m_opt).max())
+    Ld = np.tril(l.q_sqrt.numpy()[0])
+    assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-8 * max(1.0, np.abs(S_opt).max())
+    # the hidden layer did not move and its samples are X
+    assert np.abs(m.layers[0].q_mu.numpy()).max() == 0.0
+    Fs, _, _ = ctx.propagate(X[:100], S, 3, [z[:, :100] for z in zs])
+    assert np.abs(np.asarray(Fs[0]) - X[None, :100]).max() < 1e-12
