@@ -1921,3 +1921,44 @@ def test_two_layer_model_with_a_silent_hidden_layer_against_the_collapsed_bound(
     assert np.abs(m.layers[0].q_mu.numpy()).max() == 0.0
     Fs, _, _ = ctx.propagate(X[:100], S, 3, [z[:, :100] for z in zs])
     assert np.abs(np.asarray(Fs[0]) - X[None, :100]).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2000, 3, 64, 3), (30_000, 8, 256, 2)], ids=["N2000_M64", "N30000_M256"])
+def test_two_layer_model_with_given_normals_against_the_collapsed_bound_of_the_sampled_inputs(shape):
+    """The doubly-stochastic data path against a closed form.  Hidden layer at the prior: its conditional is mean = x, var = sigma_1^2
+    exactly (kdiag - Qnn + Qnn), so with GIVEN normals z its samples are F1[s] = X + sqrt(sigma_1^2 + jitter) z[s] (layers.py:87-130,
+    utils.py:17-30).  The data term (1/S) sum_s sum_n E log N(y_n | f(F1[s]_n), sigma^2) (dgp.py:89-100) is, up to a constant, the
+    log-likelihood of SVGP regression on the S N sampled inputs with noise S sigma^2; one natural-gradient step of size one on the
+    output layer must therefore reach   collapsed_bound(F1, tiled Y; noise S sigma^2) + S N [log(2 pi S sigma^2) / 2 - log(2 pi sigma^2) / (2 S)]."""
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    from helpers import collapsed_bound
+    import io, contextlib
+    N, D, M, S = shape
+    rng = np.random.default_rng(9)
+    X = rng.standard_normal((N, D))
+    Y = np.sin(2 * X[:, :1]) + 0.3 * rng.standard_normal((N, 1))
+    Z = X[rng.permutation(N)[:M]].copy()
+    ls2 = np.linspace(0.9, 1.4, D)
+    s1, s2, noise = 0.05, 1.1, 0.25
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = DGP(X, Y, Z, [RBF(s1, np.ones(D)), RBF(s2, ls2)], [D], Gaussian(variance=noise), num_samples=S)
+    ctx = m._sync_model()
+    m._sync_data(m.data)
+    zs = [rng.standard_normal((S, N, D)), np.zeros((S, N, 1))]
+    F1 = X[None] + np.sqrt(s1 + 1e-6) * zs[0]
+    Fs, _, _ = ctx.propagate(X, S, 3, zs)
+    assert np.abs(np.asarray(Fs[0]) - F1).max() < 1e-12
+    ctx.grad_partial(S, 1, zs)
+    ctx.grad_finish()
+    ctx.natgrad_step(1.0, [False, True])
+    m._device_newer = True
+    data, kl = ctx.elbo(S, 2, zs)
+    bound, m_opt, S_opt = collapsed_bound(F1.reshape(S * N, D), np.tile(Y, (S, 1)), Z, s2, ls2, S * noise, 1e-6)
+    bound += S * N * (0.5 * np.log(2 * np.pi * S * noise) - 0.5 / S * np.log(2 * np.pi * noise))
+    assert abs((data - kl) - bound) < 1e-9 * abs(bound), (data - kl, bound)
+    l = m.layers[1]
+    assert np.abs(l.q_mu.numpy() - m_opt).max() < 1e-8 * max(1.0, np.abs(m_opt).max())
+    Ld = np.tril(l.q_sqrt.numpy()[0])
+    assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-8 * max(1.0, np.abs(S_opt).max())

@@ -423,3 +423,33 @@ def test_oracle_hyperparameter_gradients_at_the_optimal_q_are_those_of_the_colla
     for k in want:
         assert abs(got[k] - want[k]) < 2e-6 * scale, (k, got[k], want[k])
     assert np.abs(G[(0, "q_mu")]).max() < 1e-6 * scale and np.abs(np.tril(np.asarray(G[(0, "q_sqrt")])[0])).max() < 1e-6 * scale
+
+
+def test_oracle_two_layer_data_path_against_the_collapsed_bound_of_the_sampled_inputs():
+    """The oracle's doubly-stochastic data path against the closed form of tests/test_gpu_parity.py::
+    test_two_layer_model_with_given_normals_...: hidden layer at the prior (samples F1[s] = X + sqrt(sigma_1^2 + jitter) z[s]), one
+    natural-gradient step of size one on the output layer, bound = collapsed bound on the S N sampled inputs with noise S sigma^2 + const."""
+    import dgp_oracle_torch as T
+    from helpers import collapsed_bound
+    N, D, M, S = 400, 2, 30, 3
+    rng = np.random.default_rng(9)
+    X = rng.standard_normal((N, D))
+    Y = np.sin(2 * X[:, :1]) + 0.3 * rng.standard_normal((N, 1))
+    Z = X[rng.permutation(N)[:M]].copy()
+    ls2 = np.array([0.9, 1.4])
+    s1, s2, noise = 0.05, 1.1, 0.25
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(s1, np.ones(D)), O.RBF(s2, ls2)], [D], lik_variance=noise, num_samples=S)
+    zs = [rng.standard_normal((S, N, D)), np.zeros((S, N, 1))]
+    F1 = X[None] + np.sqrt(s1 + O.JITTER) * zs[0]
+    Fs = mo.propagate(X, S, zs)[0]
+    assert np.abs(np.asarray(Fs[0]) - F1).max() < 1e-12
+    _, G = T.elbo_and_grads(mo, zs)
+    l = mo.layers[1]
+    l.q_mu, l.q_sqrt = O.natgrad_step(l.q_mu, l.q_sqrt, -np.asarray(G["layers"][1]["q_mu"]), -np.asarray(G["layers"][1]["q_sqrt"]), 1.0)
+    bound, m_opt, S_opt = collapsed_bound(F1.reshape(S * N, D), np.tile(Y, (S, 1)), Z, s2, ls2, S * noise, O.JITTER)
+    bound += S * N * (0.5 * np.log(2 * np.pi * S * noise) - 0.5 / S * np.log(2 * np.pi * noise))
+    e = mo.ELBO(zs)
+    assert abs(e - bound) < 1e-9 * abs(bound), (e, bound)
+    assert np.abs(l.q_mu - m_opt).max() < 1e-9
+    Ld = np.tril(l.q_sqrt[0])
+    assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-9
