@@ -131,3 +131,31 @@ def sparse_gp_predict(X, Y, Z, Xnew, variance, lengthscales, noise, jitter, kind
     As = sla.solve_triangular(L, k(Z, Xnew), lower=True)                  # L^-1 Ku*
     Bs = sla.solve_triangular(LB, As, lower=True)                         # LB^-1 L^-1 Ku*
     return Bs.T @ c, (variance - (As * As).sum(0) + (Bs * Bs).sum(0))[:, None] * np.ones((1, Y.shape[1]))
+
+
+def svgp_elbo(X, Y, Z, variance, lengthscales, noise, q_mu, q_sqrt, jitter, kind="rbf", white=False):
+    """The SVGP regression bound at an ARBITRARY q(u) = N(q_mu, q_sqrt q_sqrt^T) (Hensman et al. 2013, eq. 4), from the textbook:
+        sum_n [ log N(y_n | mu_n, noise) - v_n / (2 noise) ] - sum_d KL[ N(m_d, S_d) || N(0, Kuu) ],
+        mu = Kfu Kuu^-1 m,   v_n = k_nn - (Kfu Kuu^-1 Kuf)_nn + (Kfu Kuu^-1 S Kuu^-1 Kuf)_nn;
+    white=True: q is over v with u = chol(Kuu) v.  q_mu [M, Dy], q_sqrt [Dy, M, M] (lower triangles used)."""
+    import scipy.linalg as sla
+    N, M, Dy = X.shape[0], Z.shape[0], Y.shape[1]
+    Kuu = stationary_kernel(Z, Z, variance, lengthscales, kind) + jitter * np.eye(M)
+    Kuf = stationary_kernel(Z, X, variance, lengthscales, kind)
+    L = np.linalg.cholesky(Kuu)
+    A = sla.solve_triangular(L, Kuf, lower=True)                       # L^-1 Kuf
+    total = 0.0
+    for d in range(Dy):
+        Lq = np.tril(q_sqrt[d])
+        if white:
+            mv, Lv = q_mu[:, d], Lq                                   # v-space
+        else:
+            mv = sla.solve_triangular(L, q_mu[:, d], lower=True)      # v = L^-1 u
+            Lv = sla.solve_triangular(L, Lq, lower=True)
+        mu = A.T @ mv
+        B = Lv.T @ A                                                   # [M, N]: (L^-1 Lq)^T L^-1 Kuf
+        v = variance - (A * A).sum(0) + (B * B).sum(0)
+        total += (-0.5 * np.log(2 * np.pi * noise) - 0.5 * ((Y[:, d] - mu) ** 2 + v) / noise).sum()
+        # KL[N(mv, Lv Lv^T) || N(0, I)] in v-space (equal to the u-space KL against N(0, Kuu))
+        total -= 0.5 * ((Lv * Lv).sum() + mv @ mv - M) - np.log(np.abs(np.diag(Lv))).sum()
+    return float(total)

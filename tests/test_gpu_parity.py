@@ -1962,3 +1962,49 @@ def test_two_layer_model_with_given_normals_against_the_collapsed_bound_of_the_s
     assert np.abs(l.q_mu.numpy() - m_opt).max() < 1e-8 * max(1.0, np.abs(m_opt).max())
     Ld = np.tril(l.q_sqrt.numpy()[0])
     assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-8 * max(1.0, np.abs(S_opt).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(700, 3, 64, 2, 2, False), (700, 3, 64, 2, 2, True), (20_000, 8, 256, 1, 2, False), (20_000, 8, 256, 1, 2, True)],
+                         ids=["N700_M64_Dy2", "white_N700_M64_Dy2", "N20000_M256", "white_N20000_M256"])
+def test_elbo_and_q_gradients_at_an_arbitrary_q_against_the_textbook_svgp_bound(shape):
+    """One layer, RANDOM q(u) (not the optimum): dgp_elbo against the SVGP bound written from Hensman et al. 2013
+    (tests/helpers.py::svgp_elbo), and d ELBO / d(q_mu, q_sqrt) - the m-bar / Gram-kernel side of the hand-written backward pass
+    (G_d = sum_p vbar c c^T, W-bar = 2 G W, the KL gradients) - against central differences of that closed form along random
+    directions.  No oracle, no autograd."""
+    from helpers import svgp_elbo
+    N, D, M, Dy, S, white = shape
+    noise, var = 0.37, 1.3
+    m, X, Y, Z, ls = _one_layer_model(N, D, M, Dy, noise, S, white=white)
+    l = m.layers[0]
+    q_mu, q_sqrt = l.q_mu.numpy().copy(), np.tril(l.q_sqrt.numpy()).copy()
+    want = svgp_elbo(X, Y, Z, var, ls, noise, q_mu, q_sqrt, 1e-6, white=white)
+    c = m._grad_step(m.data)
+    assert abs(c.last_elbo() - want) < 1e-9 * abs(want), (c.last_elbo(), want)
+    G = split_flat(m, c.grad_get())
+    rng = np.random.default_rng(13)
+    h = 1e-5
+    for t in range(3):
+        Vm = rng.standard_normal(q_mu.shape)
+        Vs = np.tril(rng.standard_normal(q_sqrt.shape))
+        nrm = np.sqrt((Vm * Vm).sum() + (Vs * Vs).sum())
+        Vm, Vs = Vm / nrm, Vs / nrm
+        fd = (svgp_elbo(X, Y, Z, var, ls, noise, q_mu + h * Vm, q_sqrt + h * Vs, 1e-6, white=white)
+              - svgp_elbo(X, Y, Z, var, ls, noise, q_mu - h * Vm, q_sqrt - h * Vs, 1e-6, white=white)) / (2 * h)
+        an = float((G[(0, "q_mu")] * Vm).sum() + (np.tril(G[(0, "q_sqrt")]) * Vs).sum())
+        assert abs(fd - an) < 1e-6 * max(1.0, abs(an)), (t, fd, an)
+    # ... and, at the same generic state, the kernel / likelihood / inducing-input side (dK -> g -> g [Z|1], the Kuu chain with Q')
+    h = 1e-4
+
+    def bound(dvar=0.0, dls=0.0, dnoise=0.0, dZ=0.0):
+        return svgp_elbo(X, Y, Z + dZ, var + dvar, ls + dls, noise + dnoise, q_mu, q_sqrt, 1e-6, white=white)
+    V = rng.standard_normal(Z.shape)
+    V /= np.linalg.norm(V)
+    e0 = np.eye(D)[0]
+    want_g = {"var": (bound(dvar=h) - bound(dvar=-h)) / (2 * h), "noise": (bound(dnoise=h) - bound(dnoise=-h)) / (2 * h),
+              "ls0": (bound(dls=h * e0) - bound(dls=-h * e0)) / (2 * h), "Z": (bound(dZ=h * V) - bound(dZ=-h * V)) / (2 * h)}
+    got_g = {"var": float(G[(0, "variance")]), "noise": float(G[("lik", "variance")]), "ls0": float(np.ravel(G[(0, "lengthscales")])[0]),
+             "Z": float((G[(0, "Z")] * V).sum())}
+    scale = max(abs(v) for v in want_g.values())
+    for k in want_g:
+        assert abs(got_g[k] - want_g[k]) < 2e-6 * scale, (k, got_g[k], want_g[k], scale)

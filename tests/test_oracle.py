@@ -453,3 +453,24 @@ def test_oracle_two_layer_data_path_against_the_collapsed_bound_of_the_sampled_i
     assert np.abs(l.q_mu - m_opt).max() < 1e-9
     Ld = np.tril(l.q_sqrt[0])
     assert np.abs(Ld @ Ld.T - S_opt).max() < 1e-9
+
+
+@pytest.mark.parametrize("white", [False, True])
+def test_oracle_elbo_at_an_arbitrary_q_equals_the_textbook_svgp_bound(white):
+    """One layer, random q(u): the oracle's ELBO (conditional_ND, KL, variational expectations: layers.py:227-308, dgp.py:89-100)
+    against the SVGP bound written from Hensman et al. 2013 (tests/helpers.py::svgp_elbo)."""
+    from helpers import svgp_elbo
+    N, D, M, Dy = 250, 2, 18, 2
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((N, D))
+    Y = np.stack([np.sin(2 * X[:, 0]), np.cos(X[:, 1])], 1) + 0.2 * rng.standard_normal((N, Dy))
+    Z = X[:M].copy()
+    ls = np.array([0.7, 1.3])
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(1.4, ls)], [], lik_variance=0.3, white=white, num_samples=2)
+    l = mo.layers[0]
+    l.q_mu = 0.4 * rng.standard_normal((M, Dy))
+    l.q_sqrt = np.stack([np.tril(0.5 * np.eye(M) + 0.1 * rng.standard_normal((M, M))) for _ in range(Dy)])
+    zs = [rng.standard_normal((2, N, Dy))]
+    want = svgp_elbo(X, Y, Z, 1.4, ls, 0.3, l.q_mu, l.q_sqrt, O.JITTER, white=white)
+    got = mo.ELBO(zs)
+    assert abs(got - want) < 1e-10 * abs(want), (got, want)
