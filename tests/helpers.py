@@ -159,3 +159,35 @@ def svgp_elbo(X, Y, Z, variance, lengthscales, noise, q_mu, q_sqrt, jitter, kind
         # KL[N(mv, Lv Lv^T) || N(0, I)] in v-space (equal to the u-space KL against N(0, Kuu))
         total -= 0.5 * ((Lv * Lv).sum() + mv @ mv - M) - np.log(np.abs(np.diag(Lv))).sum()
     return float(total)
+
+
+def svgp_moments(Xin, Z, variance, lengthscales, q_mu, q_sqrt, jitter, kind="rbf"):
+    """Marginal mean / variance of the SVGP posterior at Xin (Hensman et al. 2013, eq. 3), one column per output, and the KL:
+        mu = Kfu Kuu^-1 m,  v = k_nn - diag(Kfu Kuu^-1 Kuf) + diag(Kfu Kuu^-1 S Kuu^-1 Kuf),  KL = sum_d KL[N(m_d, S_d) || N(0, Kuu)]."""
+    import scipy.linalg as sla
+    M, Dy = Z.shape[0], q_mu.shape[1]
+    L = np.linalg.cholesky(stationary_kernel(Z, Z, variance, lengthscales, kind) + jitter * np.eye(M))
+    A = sla.solve_triangular(L, stationary_kernel(Z, Xin, variance, lengthscales, kind), lower=True)
+    mu, v, kl = np.empty((Xin.shape[0], Dy)), np.empty((Xin.shape[0], Dy)), 0.0
+    for d in range(Dy):
+        mv = sla.solve_triangular(L, q_mu[:, d], lower=True)
+        Lv = sla.solve_triangular(L, np.tril(q_sqrt[d]), lower=True)
+        B = Lv.T @ A
+        mu[:, d] = A.T @ mv
+        v[:, d] = variance - (A * A).sum(0) + (B * B).sum(0)
+        kl += 0.5 * ((Lv * Lv).sum() + mv @ mv - M) - np.log(np.abs(np.diag(Lv))).sum()
+    return mu, v, float(kl)
+
+
+def dsdgp2_elbo(X, Y, z1, layer1, layer2, noise, jitter):
+    """Doubly-stochastic bound of a two-layer DGP (Salimbeni & Deisenroth 2017, eq. 13-16) for GIVEN hidden-layer normals z1 [S, N, D1],
+    identity mean function on the hidden layer, zero on the output layer; layer = dict(Z, variance, lengthscales, q_mu, q_sqrt):
+        F1[s] = X + mu1(X) + sqrt(v1(X) + jitter) z1[s];   ELBO = (1/S) sum_s sum_n E_q2[log N(y_n | f2(F1[s]_n), noise)] - KL1 - KL2."""
+    S = z1.shape[0]
+    mu1, v1, kl1 = svgp_moments(X, layer1["Z"], layer1["variance"], layer1["lengthscales"], layer1["q_mu"], layer1["q_sqrt"], jitter)
+    total, kl2 = 0.0, 0.0
+    for s in range(S):
+        F1 = X + mu1 + np.sqrt(v1 + jitter) * z1[s]
+        mu2, v2, kl2 = svgp_moments(F1, layer2["Z"], layer2["variance"], layer2["lengthscales"], layer2["q_mu"], layer2["q_sqrt"], jitter)
+        total += (-0.5 * np.log(2 * np.pi * noise) - 0.5 * ((Y - mu2) ** 2 + v2) / noise).sum()
+    return float(total / S - kl1 - kl2)

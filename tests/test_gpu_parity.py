@@ -2008,3 +2008,67 @@ def test_elbo_and_q_gradients_at_an_arbitrary_q_against_the_textbook_svgp_bound(
     scale = max(abs(v) for v in want_g.values())
     for k in want_g:
         assert abs(got_g[k] - want_g[k]) < 2e-6 * scale, (k, got_g[k], want_g[k], scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1500, 3, 64, 2), (20_000, 8, 256, 2)], ids=["N1500_M64", "N20000_M256"])
+def test_two_layer_elbo_and_gradients_through_the_hidden_layer_against_the_bound_written_from_the_paper(shape):
+    """Two layers, random q(u) in BOTH, given normals.  dgp_elbo against tests/helpers.py::dsdgp2_elbo (Salimbeni & Deisenroth 2017
+    eq. 13-16 assembled from the SVGP marginals of Hensman et al. 2013), and the gradient of every parameter family of BOTH layers
+    against central differences of that function along random directions: for the hidden layer this is the chain THROUGH the sampled
+    inputs of the layer above (g^T [X|1] -> x-bar -> fold -> m-bar, v-bar of the layer below; dgp.py:272-275 is what the reference's
+    tape derives) - checked without oracle or autograd."""
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    from helpers import dsdgp2_elbo, stationary_kernel
+    import io, contextlib
+    N, D, M, S = shape
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((N, D))
+    Y = np.sin(2 * X[:, :1]) + 0.3 * rng.standard_normal((N, 1))
+    Z = X[rng.permutation(N)[:M]].copy()
+    kp = [(0.6, np.linspace(0.9, 1.2, D)), (1.1, np.linspace(1.3, 0.8, D))]
+    noise = 0.25
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = DGP(X, Y, Z, [RBF(v, l) for v, l in kp], [D], Gaussian(variance=noise), num_samples=S)
+    lay = []
+    for l, (v, ls), dout in zip(m.layers, kp, (D, 1)):
+        Lu = np.linalg.cholesky(stationary_kernel(Z, Z, v, ls) + 1e-6 * np.eye(M))
+        q_mu = Lu @ (0.4 * rng.standard_normal((M, dout)))
+        q_sqrt = np.stack([np.tril(Lu @ np.tril(0.5 * np.eye(M) + 0.1 * rng.standard_normal((M, M)))) for _ in range(dout)])
+        l.q_mu.assign(q_mu)
+        l.q_sqrt.assign(q_sqrt)
+        lay.append(dict(Z=Z.copy(), variance=v, lengthscales=ls.copy(), q_mu=q_mu, q_sqrt=q_sqrt))
+    ctx = m._sync_model()
+    m._sync_data(m.data)
+    zs = [rng.standard_normal((S, N, D)), np.zeros((S, N, 1))]
+    want = dsdgp2_elbo(X, Y, zs[0], lay[0], lay[1], noise, 1e-6)
+    ctx.grad_partial(S, 1, zs)
+    got = ctx.grad_finish(want_elbo=True)
+    assert abs(got - want) < 1e-9 * abs(want), (got, want)
+    G = split_flat(m, ctx.grad_get())
+
+    def fd(i, key, V, h):
+        out = []
+        for sgn in (+1, -1):
+            L2 = [dict(a) for a in lay]
+            L2[i][key] = L2[i][key] + sgn * h * V
+            out.append(dsdgp2_elbo(X, Y, zs[0], L2[0], L2[1], noise, 1e-6))
+        return (out[0] - out[1]) / (2 * h)
+    name = {"Z": "Z", "variance": "variance", "lengthscales": "lengthscales", "q_mu": "q_mu", "q_sqrt": "q_sqrt"}
+    rows = []
+    for i in (0, 1):
+        for key in ("q_mu", "q_sqrt", "Z", "lengthscales", "variance"):
+            ref = np.asarray(lay[i][key], dtype=float)
+            V = rng.standard_normal(ref.shape) if ref.ndim else np.float64(1.0)
+            if key == "q_sqrt":
+                V = np.tril(V)
+            V = V / np.sqrt((V * V).sum())
+            g = G[(i, name[key])]
+            if key == "q_sqrt":
+                g = np.tril(g)
+            an = float((np.asarray(g).reshape(np.shape(V)) * V).sum())
+            rows.append((i, key, fd(i, key, V, 1e-5 if key in ("q_mu", "q_sqrt") else 1e-4), an))
+    scale = max(abs(r[2]) for r in rows)
+    for i, key, f, an in rows:
+        assert abs(f - an) < 5e-6 * scale, (i, key, f, an, scale)

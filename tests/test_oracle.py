@@ -474,3 +474,25 @@ def test_oracle_elbo_at_an_arbitrary_q_equals_the_textbook_svgp_bound(white):
     want = svgp_elbo(X, Y, Z, 1.4, ls, 0.3, l.q_mu, l.q_sqrt, O.JITTER, white=white)
     got = mo.ELBO(zs)
     assert abs(got - want) < 1e-10 * abs(want), (got, want)
+
+
+def test_oracle_two_layer_elbo_at_arbitrary_q_equals_the_bound_written_from_the_paper():
+    """Two layers, random q(u) in both, given normals: the oracle's ELBO against tests/helpers.py::dsdgp2_elbo (Salimbeni & Deisenroth
+    2017 eq. 13-16 assembled from the SVGP marginals of Hensman et al. 2013)."""
+    from helpers import dsdgp2_elbo
+    N, D, M, S = 300, 2, 20, 3
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((N, D))
+    Y = np.sin(2 * X[:, :1]) + 0.3 * rng.standard_normal((N, 1))
+    Z = X[rng.permutation(N)[:M]].copy()
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(0.6, np.array([0.9, 1.2])), O.RBF(1.1, np.array([1.3, 0.8]))], [D], lik_variance=0.25, num_samples=S)
+    lay = []
+    for l, dout in zip(mo.layers, (D, 1)):
+        l.build_cholesky()
+        l.q_mu = l.Lu @ (0.4 * rng.standard_normal((M, dout)))
+        l.q_sqrt = np.stack([np.tril(l.Lu @ np.tril(0.5 * np.eye(M) + 0.1 * rng.standard_normal((M, M)))) for _ in range(dout)])
+        lay.append(dict(Z=np.asarray(l.Z), variance=l.kern.variance, lengthscales=np.asarray(l.kern.lengthscales), q_mu=l.q_mu, q_sqrt=l.q_sqrt))
+    zs = [rng.standard_normal((S, N, D)), np.zeros((S, N, 1))]
+    want = dsdgp2_elbo(X, Y, zs[0], lay[0], lay[1], 0.25, O.JITTER)
+    got = mo.ELBO(zs)
+    assert abs(got - want) < 1e-10 * abs(want), (got, want)
