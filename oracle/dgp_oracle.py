@@ -18,11 +18,17 @@ Keras ``Adam``) restated from their published definitions
 TensorFlow and TFP are not installed in the build container and cannot be fetched; their
 version is unpinned by the reference (README says "GPflow 2.0").
 
-Parity pin: the reference has no tests.  The oracle is pinned by the two known answers its
-notebook stores (``Notebooks_dgp/nb_DGP_regression.ipynb`` cells 22/26 and 30):
-``ELBO == -85.98812279560475`` for the freshly built model and
-``number_parameters(trainable=False) == 2032`` (tests/test_oracle.py).  Everything else is
-pinned by self-consistency (NumPy restatement vs torch-autograd twin vs finite differences).
+Parity pin: the reference has no tests.  The oracle is pinned by the three known answers its
+notebooks store - ``ELBO == -85.98812279560475`` for the freshly built model and
+``number_parameters(trainable=False) == 2032`` (``Notebooks_dgp/nb_DGP_regression.ipynb`` cells
+22/26 and 30), ``ELBO: -73.6722504558447`` (``nb_dgp_BO.ipynb`` cells 30/61: the non-white KL at
+q != prior through ``SO_BO``) - and, since round 4, by closed forms written from the literature in
+``tests/helpers.py`` (not from the reference's code): Titsias' collapsed bound, its optimal q(u)
+and predictive equations (one natural-gradient step of size one must land there), the SVGP bound
+at an arbitrary q(u) (Hensman et al. 2013) and the two-layer doubly-stochastic bound for given
+normals (Salimbeni & Deisenroth 2017), each with its central differences for the gradients
+(tests/test_oracle.py).  The Adam trajectories rest on self-consistency (NumPy restatement vs
+torch-autograd twin).
 """
 from __future__ import annotations
 
