@@ -191,3 +191,27 @@ def dsdgp2_elbo(X, Y, z1, layer1, layer2, noise, jitter):
         mu2, v2, kl2 = svgp_moments(F1, layer2["Z"], layer2["variance"], layer2["lengthscales"], layer2["q_mu"], layer2["q_sqrt"], jitter)
         total += (-0.5 * np.log(2 * np.pi * noise) - 0.5 * ((Y - mu2) ** 2 + v2) / noise).sum()
     return float(total / S - kl1 - kl2)
+
+
+def dsdgp_elbo(X, Y, zs, layers, noise, jitter):
+    """The doubly-stochastic bound for any depth (Salimbeni & Deisenroth 2017, eq. 13-16), GIVEN the normals of every hidden layer
+    (zs[l]: [S, N, D_l]); identity mean function on the hidden layers (equal widths), zero on the last; layers[l] = dict(Z, variance,
+    lengthscales, q_mu, q_sqrt).  The first layer's marginals do not depend on the sample (dgp.py:49 tiles X first)."""
+    S = zs[0].shape[0]
+    kls = []
+    mu0, v0, kl0 = svgp_moments(X, layers[0]["Z"], layers[0]["variance"], layers[0]["lengthscales"], layers[0]["q_mu"], layers[0]["q_sqrt"], jitter)
+    kls.append(kl0)
+    if len(layers) == 1:
+        return float((-0.5 * np.log(2 * np.pi * noise) - 0.5 * ((Y - mu0) ** 2 + v0) / noise).sum() - kl0)
+    total = 0.0
+    for s in range(S):
+        F = X + mu0 + np.sqrt(v0 + jitter) * zs[0][s]
+        for l in range(1, len(layers)):
+            L = layers[l]
+            mu, v, kl = svgp_moments(F, L["Z"], L["variance"], L["lengthscales"], L["q_mu"], L["q_sqrt"], jitter)
+            if s == 0:
+                kls.append(kl)
+            if l < len(layers) - 1:
+                F = F + mu + np.sqrt(v + jitter) * zs[l][s]
+        total += (-0.5 * np.log(2 * np.pi * noise) - 0.5 * ((Y - mu) ** 2 + v) / noise).sum()
+    return float(total / S - sum(kls))
