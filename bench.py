@@ -317,11 +317,50 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, num_units, X, Y, Z)
             out["elbo_rel_err_vs_oracle"] = out["cpu_baseline"].pop("elbo_rel_err")
+            if not args.minibatch and len(set(dims)) == 1:
+                out["elbo_vs_closed_form"] = closed_form_check(args, num_units, X, Y, Z, local_rank)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def closed_form_check(args, num_units, X, Y, Z, device):
+    """`fp64 ELBO match` of BASELINE.json's metric at the FULL workload, against a formula rather than a program: a second model of the
+    same shape with a random q(u) in every layer and given normals; dgp_elbo on the device against the doubly-stochastic bound assembled
+    from the papers' formulas in NumPy (tests/helpers.py::dsdgp_elbo - Salimbeni & Deisenroth 2017 eq. 13-16 over the SVGP marginals of
+    Hensman et al. 2013; identity mean functions, so equal layer widths only).  ~30 s of host time at config 2."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import dsdgp_elbo, stationary_kernel
+    from dgp_dace.gpflow_compat import RBF, Gaussian
+    from dgp_dace.models.dgp import DGP
+    rng = np.random.default_rng(16)
+    D, M, S, N = args.D, args.M, args.S, args.N
+    kp = [(0.5 + 0.2 * i, np.linspace(0.9, 1.3, D) + 0.05 * i) for i in range(len(num_units) + 1)]
+    noise = 0.25
+    stdout = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+    m = DGP(X, Y, Z, [RBF(v, l) for v, l in kp], num_units, Gaussian(variance=noise), num_samples=S, seed=0, device=device)
+    sys.stdout = stdout
+    lay = []
+    for l, (v, ls), dout in zip(m.layers, kp, num_units + [Y.shape[1]]):
+        Lu = np.linalg.cholesky(stationary_kernel(Z, Z, v, ls) + 1e-6 * np.eye(M))
+        q_mu = Lu @ (0.3 * rng.standard_normal((M, dout)))
+        q_sqrt = np.stack([np.tril(Lu @ np.tril(0.4 * np.eye(M) + 0.5 / M * rng.standard_normal((M, M)))) for _ in range(dout)])
+        l.q_mu.assign(q_mu)
+        l.q_sqrt.assign(q_sqrt)
+        lay.append(dict(Z=np.asarray(l.feature.Z.numpy()), variance=v, lengthscales=ls.copy(), q_mu=q_mu, q_sqrt=q_sqrt))
+    ctx = m._sync_model()
+    m._sync_data(m.data)
+    zs = [rng.standard_normal((S, N, d)) for d in num_units] + [np.zeros((S, N, Y.shape[1]))]
+    data, kl = ctx.elbo(S, 1, zs)
+    t0 = time.perf_counter()
+    want = dsdgp_elbo(X, Y, zs, lay, noise, 1e-6)
+    dt = time.perf_counter() - t0
+    return {"rel_err": abs((data - kl) - want) / abs(want), "elbo_device": data - kl, "elbo_closed_form": want, "host_seconds": dt,
+            "what": f"dgp_elbo of a model of the bench's shape (num_units={num_units}, N={N}, D={D}, M={M}, S={S}; random q(u) in every layer, "
+                    "given normals) against tests/helpers.py::dsdgp_elbo (the doubly-stochastic bound from the papers' formulas, NumPy)"}
 
 
 def cpu_model_name():
