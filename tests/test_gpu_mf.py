@@ -386,3 +386,102 @@ def test_mf_propagate_full_cov_matches_the_restatement(n_fid):
     assert np.all(np.linalg.eigvalsh(cov) > 0)
     m1, c1 = mf.predict(Xt[:1], full_cov=True)                      # N = 1: the reference's own expression is defined
     assert m1.shape == (1, 1) and c1.shape == (1, 1) and c1[0, 0] > 0
+
+
+def _mf_kernel_numpy(A, B, Dx, hyp):
+    """The multi-fidelity layer kernel as MF_DGP_EM.py:341-367 composes it from gpflow kernels, in NumPy from the definitions of those
+    kernels:  k = k_corr(x, x') * (k_prev(f, f') + k_lin(f, f')) + k_in(x, x'),  inputs [x (Dx columns), f (last column)],
+    squared-exponential k_corr / k_prev / k_in, k_lin = variance * f f'."""
+    vc, lc, vp, lp, vl, vi, li = hyp
+
+    def se(U, V, var, ls):
+        U, V = U / ls, V / ls
+        d2 = np.maximum((U * U).sum(1)[:, None] + (V * V).sum(1)[None, :] - 2.0 * U @ V.T, 0.0)
+        return var * np.exp(-0.5 * d2)
+    xa, xb, fa, fb = A[:, :Dx], B[:, :Dx], A[:, Dx:], B[:, Dx:]
+    return se(xa, xb, vc, lc) * (se(fa, fb, vp, lp) + vl * fa @ fb.T) + se(xa, xb, vi, li)
+
+
+@pytest.mark.parametrize("white,D_out", [(False, 1), (True, 2)])
+def test_mf_kernel_layer_against_the_svgp_marginals_written_from_the_definitions(white, D_out):
+    """One SVGP layer with the multi-fidelity kernel (csrc/mfkern.hip) at a random q(u): mean, variance, samples and KL on the device
+    against the SVGP marginals of Hensman et al. 2013 evaluated in NumPy with the kernel composed from its definition - a check of the
+    MF pieces that does not pass through oracle/mf_dgp_em_oracle.py."""
+    import scipy.linalg as sla
+    from dgp_dace import _native
+    rng = np.random.default_rng(5)
+    layer, names, flat, desc, X = _layer_case("mf", white, D_out, rng)
+    P, Din = X.shape
+    M, Dx = desc[2], Din - 1
+    Z = layer["Z"].detach().numpy()
+    hyp = [float(layer["kern"][n].detach()) for n in names[:7]]
+    wv = 0.07 if white else 0.0
+    q_mu, q_sqrt = layer["q_mu"].detach().numpy(), layer["q_sqrt"].detach().numpy()
+    L = np.linalg.cholesky(_mf_kernel_numpy(Z, Z, Dx, hyp) + (wv + 1e-6) * np.eye(M))
+    A = sla.solve_triangular(L, _mf_kernel_numpy(Z, X, Dx, hyp), lower=True)
+    kdiag = np.diag(_mf_kernel_numpy(X, X, Dx, hyp)) + wv
+    z = rng.standard_normal((1, P, D_out))
+    ctx = _native.Context(0)
+    ctx.model_set([desc], flat, None)
+    Fs, Fm, Fv = ctx.propagate(X, 1, 0, [z])
+    kl = 0.0
+    for d in range(D_out):
+        mv = sla.solve_triangular(L, q_mu[:, d], lower=True)
+        Lv = sla.solve_triangular(L, np.tril(q_sqrt[d]), lower=True)
+        B = Lv.T @ A
+        mean = A.T @ mv
+        var = kdiag - (A * A).sum(0) + (B * B).sum(0)
+        np.testing.assert_allclose(Fm[0][0][:, d], mean, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(Fv[0][0][:, d], var, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(Fs[0][0][:, d], mean + z[0][:, d] * np.sqrt(var + 1e-6), rtol=1e-8, atol=1e-10)
+        kl += 0.5 * ((Lv * Lv).sum() + mv @ mv - M) - np.log(np.abs(np.diag(Lv))).sum()
+    ctx.propagate_vjp(X, 1, 0, [z], f_bar=np.zeros((1, P, D_out)), mean_bar=np.zeros((1, P, D_out)), var_bar=np.zeros((1, P, D_out)), accumulate="reset")
+    minus_kl = ctx.grad_finish(want_elbo=True)
+    assert abs(minus_kl + kl) <= 1e-9 * max(1.0, abs(kl)), (minus_kl, kl)
+
+    # the parameter gradients of  sum(fb F + mb mean + vb var) - KL  against central differences of the same NumPy function
+    fb, mb, vb = (rng.standard_normal((1, P, D_out)) for _ in range(3))
+
+    def objective(Zv, hv, wvv, qm, qs):
+        Lx = np.linalg.cholesky(_mf_kernel_numpy(Zv, Zv, Dx, hv) + (wvv + 1e-6) * np.eye(M))
+        Ax = sla.solve_triangular(Lx, _mf_kernel_numpy(Zv, X, Dx, hv), lower=True)
+        kd = np.diag(_mf_kernel_numpy(X, X, Dx, hv)) + wvv
+        tot = 0.0
+        for d in range(D_out):
+            mv = sla.solve_triangular(Lx, qm[:, d], lower=True)
+            Lv = sla.solve_triangular(Lx, np.tril(qs[d]), lower=True)
+            Bx = Lv.T @ Ax
+            mean = Ax.T @ mv
+            var = kd - (Ax * Ax).sum(0) + (Bx * Bx).sum(0)
+            F = mean + z[0][:, d] * np.sqrt(var + 1e-6)
+            tot += (fb[0][:, d] * F + mb[0][:, d] * mean + vb[0][:, d] * var).sum()
+            tot -= 0.5 * ((Lv * Lv).sum() + mv @ mv - M) - np.log(np.abs(np.diag(Lv))).sum()
+        return tot
+    ctx.propagate_vjp(X, 1, 0, [z], f_bar=fb, mean_bar=mb, var_bar=vb, accumulate="reset")
+    ctx.grad_finish()
+    g = ctx.grad_get()
+    h = 1e-6
+    base = (Z, list(hyp), wv, q_mu, q_sqrt)
+    off = M * Din
+    nk = 7 + (1 if white else 0)
+    for j in range(nk):
+        def shifted(e):
+            hv, w2 = list(hyp), wv
+            if j < 7:
+                hv[j] += e
+            else:
+                w2 += e
+            return objective(Z, hv, w2, q_mu, q_sqrt)
+        fd = (shifted(h) - shifted(-h)) / (2 * h)
+        assert abs(g[off + j] - fd) < 1e-6 * max(1.0, abs(fd)), (names[j], g[off + j], fd)
+    VZ = rng.standard_normal(Z.shape)
+    VZ /= np.linalg.norm(VZ)
+    fdz = (objective(Z + h * VZ, hyp, wv, q_mu, q_sqrt) - objective(Z - h * VZ, hyp, wv, q_mu, q_sqrt)) / (2 * h)
+    assert abs((g[:M * Din].reshape(M, Din) * VZ).sum() - fdz) < 1e-6 * max(1.0, abs(fdz))
+    Vm, Vs = rng.standard_normal(q_mu.shape), np.tril(rng.standard_normal(q_sqrt.shape))
+    nrm = np.sqrt((Vm * Vm).sum() + (Vs * Vs).sum())
+    Vm, Vs = Vm / nrm, Vs / nrm
+    fdq = (objective(Z, hyp, wv, q_mu + h * Vm, q_sqrt + h * Vs) - objective(Z, hyp, wv, q_mu - h * Vm, q_sqrt - h * Vs)) / (2 * h)
+    oq = off + nk
+    an = (g[oq:oq + M * D_out].reshape(M, D_out) * Vm).sum() + (np.tril(g[oq + M * D_out:oq + M * D_out + D_out * M * M].reshape(D_out, M, M)) * Vs).sum()
+    assert abs(an - fdq) < 1e-6 * max(1.0, abs(fdq)), (an, fdq)
