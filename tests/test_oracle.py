@@ -496,3 +496,26 @@ def test_oracle_two_layer_elbo_at_arbitrary_q_equals_the_bound_written_from_the_
     want = dsdgp2_elbo(X, Y, zs[0], lay[0], lay[1], 0.25, O.JITTER)
     got = mo.ELBO(zs)
     assert abs(got - want) < 1e-10 * abs(want), (got, want)
+
+
+def test_oracle_three_layer_elbo_equals_the_bound_for_any_depth():
+    """tests/helpers.py::dsdgp_elbo (the function bench.py's elbo_vs_closed_form and the full-size GPU test use) against the oracle on a
+    three-layer model with a random q(u) in every layer and given normals."""
+    from helpers import dsdgp_elbo
+    N, D, M, S = 200, 2, 15, 3
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((N, D))
+    Y = np.sin(2 * X[:, :1]) + 0.3 * rng.standard_normal((N, 1))
+    Z = X[rng.permutation(N)[:M]].copy()
+    kp = [(0.5 + 0.2 * i, np.array([0.9, 1.3]) + 0.05 * i) for i in range(3)]
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(v, l) for v, l in kp], [D, D], lik_variance=0.25, num_samples=S)
+    lay = []
+    for l, dout in zip(mo.layers, (D, D, 1)):
+        l.build_cholesky()
+        l.q_mu = l.Lu @ (0.3 * rng.standard_normal((M, dout)))
+        l.q_sqrt = np.stack([np.tril(l.Lu @ np.tril(0.4 * np.eye(M) + 0.03 * rng.standard_normal((M, M)))) for _ in range(dout)])
+        lay.append(dict(Z=np.asarray(l.Z), variance=l.kern.variance, lengthscales=np.asarray(l.kern.lengthscales), q_mu=l.q_mu, q_sqrt=l.q_sqrt))
+    zs = [rng.standard_normal((S, N, D)), rng.standard_normal((S, N, D)), np.zeros((S, N, 1))]
+    want = dsdgp_elbo(X, Y, zs, lay, 0.25, O.JITTER)
+    got = mo.ELBO(zs)
+    assert abs(got - want) < 1e-10 * abs(want), (got, want)
