@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--nat-steps", type=int, default=10,
                     help="after the timed Adam region: this many part-2 iterations of optimize_nat_adam (2 evaluations + Adam + "
                          "natural gradient, dgp.py:337-345), timed the same way and reported as extra keys (0 = skip)")
+    ap.add_argument("--breakdown-steps", type=int, default=0,
+                    help="iterations of the per-category breakdown pass behind the timed region, beside which rocm-smi is sampled "
+                         "(0 = 40, or min(steps, 10) for iterations longer than 0.2 s)")
     ap.add_argument("--cpu-sample", type=int, default=8192)
     args = ap.parse_args()
 
@@ -212,14 +215,17 @@ def main():
     elbo_last = ctx.last_elbo()
 
     # ---- per-category breakdown: a pass of its own behind the timed region (every category's launches between event pairs)
-    bsteps = min(args.steps, 10)
-    ctx.prof_enable(True)
+    # (dt is the max over ranks by now: every rank runs the same number of iterations here)
+    bsteps = args.breakdown_steps if args.breakdown_steps > 0 else (40 if dt / args.steps < 0.2 else min(args.steps, 10))
+    sampler = PowerSampler(local_rank) if rank == 0 else None       # package power / shader clock beside the SAME iterations, never beside
+    ctx.prof_enable(True)                                           # the timed region (rocm-smi children on the host, nothing on the GPU)
     for _ in range(bsteps):
         step()
     fence()
     prof_all = ctx.prof_read()
     ctx.prof_enable(False)
     model._device_newer = True
+    power = sampler.stop() if sampler is not None else None
 
     # ---- the natural-gradient iteration north_star names (part 2 of optimize_nat_adam, dgp.py:337-345): one Adam step on the
     # hyper-parameters + one natural-gradient step on every layer's q(u), each behind its own ELBO evaluation with fresh normals
@@ -295,6 +301,7 @@ def main():
                               "streams BESIDE full-chip persistent kernels, so their spans include waiting for CUs and the categories "
                               "overlap: the sum exceeds ms_per_step (their own cost is ~0.9 ms per step, profiles/r3_shard_sizes.txt)",
             "elbo_last": elbo_last, "device": name,
+            "power": power,
         }
         if nat is not None:
             flops_it = 2.0 * alg_flops_step(args.minibatch or args.N, args.S, dims, args.M, 1) / world
@@ -324,6 +331,60 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class PowerSampler:
+    """Package power, shader clock and temperatures as `rocm-smi` reports them, sampled from a thread while iterations run (DESIGN.md §5:
+    the fp64 kernels sit at the package power limit, which is what bounds roofline.frac).  Best effort: None if rocm-smi is missing."""
+
+    def __init__(self, gpu):
+        import re
+        import shutil
+        import subprocess
+        import threading
+        self.gpu, self.samples, self.run = int(gpu), [], shutil.which("rocm-smi") is not None
+        self.cap = None
+
+        def loop():
+            pat = {"sclk_mhz": re.compile(r"GPU\[%d\]\s*:\s*sclk clock level: \S+ \((\d+)Mhz\)" % self.gpu),
+                   "package_w": re.compile(r"GPU\[%d\]\s*:.*Package Power \(W\):\s*([\d.]+)" % self.gpu),
+                   "junction_c": re.compile(r"GPU\[%d\]\s*:\s*Temperature \(Sensor junction\) \(C\):\s*([\d.]+)" % self.gpu),
+                   "hbm_c": re.compile(r"GPU\[%d\]\s*:\s*Temperature \(Sensor memory\) \(C\):\s*([\d.]+)" % self.gpu)}
+            while self.run:
+                try:
+                    txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showtemp"], capture_output=True, text=True, timeout=10).stdout
+                except Exception:
+                    break
+                row = {}
+                for k, p in pat.items():
+                    m = p.search(txt)
+                    if m:
+                        row[k] = float(m.group(1))
+                if "package_w" in row and "sclk_mhz" in row:
+                    self.samples.append(row)
+            try:
+                txt = subprocess.run(["rocm-smi", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
+                m = re.search(r"GPU\[%d\]\s*:.*Power \(W\):\s*([\d.]+)" % self.gpu, txt)
+                self.cap = float(m.group(1)) if m else None
+            except Exception:
+                pass
+        self.thread = threading.Thread(target=loop, daemon=True)
+        if self.run:
+            self.thread.start()
+
+    def stop(self):
+        if not self.run:
+            return None
+        self.run = False
+        self.thread.join(timeout=30)
+        busy = [r for r in self.samples if r["package_w"] > 600.0]
+        if not busy:
+            return None
+        med = lambda k: float(np.median([r[k] for r in busy if k in r])) if any(k in r for r in busy) else None
+        return {"samples": len(busy), "sclk_mhz_median": med("sclk_mhz"), "package_w_median": med("package_w"), "package_w_max": max(r["package_w"] for r in busy),
+                "package_w_cap": self.cap, "junction_c_median": med("junction_c"), "hbm_c_median": med("hbm_c"),
+                "note": "rocm-smi sampled from a host thread during the breakdown pass (the same optimize_adam iterations, behind the timed region); "
+                        "roofline.peak assumes 2400 MHz"}
 
 
 def closed_form_check(args, num_units, X, Y, Z, device):

@@ -1368,7 +1368,8 @@ def test_bench_py_multi_rank_launch_over_gloo(tmp_path, shape):
     two Adam steps with those gradients."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    args = ["--N", shape[0], "--M", shape[1], "--S", shape[2], "--num-units", shape[3], "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    args = ["--N", shape[0], "--M", shape[1], "--S", shape[2], "--num-units", shape[3], "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+            "--breakdown-steps", "2"]          # (a short trajectory: Adam amplifies summation-order noise, tests/test_oracle.py)
     port = 29700 + (os.getpid() % 2000)
     env = dict(os.environ, DGP_BENCH_BACKEND="gloo")
     cmd2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

@@ -15,7 +15,7 @@ tail -1 $O/pytest_gpu.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { echo "smoke failed"; tail -20 $O/smoke.log; exit 1; }
 tail -1 $O/smoke.log
 cd /tmp
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --nat-steps 0"
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --nat-steps 0 --breakdown-steps 2"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > /dev/null 2>&1 || { echo "pmc fetch failed"; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B > /dev/null 2>&1 || { echo "pmc write failed"; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- $B > /dev/null 2>&1 || { echo "pmc mfma failed"; exit 1; }
