@@ -344,6 +344,9 @@ class PowerSampler:
         import threading
         self.gpu, self.samples, self.run = int(gpu), [], shutil.which("rocm-smi") is not None
         self.cap = None
+        # not under a profiler: its preloaded tool would ride into every rocm-smi child
+        if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+            self.run = False
 
         def loop():
             pat = {"sclk_mhz": re.compile(r"GPU\[%d\]\s*:\s*sclk clock level: \S+ \((\d+)Mhz\)" % self.gpu),
