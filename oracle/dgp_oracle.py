@@ -27,8 +27,9 @@ q != prior through ``SO_BO``) - and, since round 4, by closed forms written from
 and predictive equations (one natural-gradient step of size one must land there), the SVGP bound
 at an arbitrary q(u) (Hensman et al. 2013) and the two-layer doubly-stochastic bound for given
 normals (Salimbeni & Deisenroth 2017), each with its central differences for the gradients
-(tests/test_oracle.py).  The Adam trajectories rest on self-consistency (NumPy restatement vs
-torch-autograd twin).
+(tests/test_oracle.py).  Multi-iteration trajectories rest on self-consistency (NumPy restatement vs
+torch-autograd twin); the product's single Adam / natural-gradient steps are checked against their
+published formulas in tests/test_gpu_parity.py.
 """
 from __future__ import annotations
 

@@ -2162,3 +2162,81 @@ def test_three_layer_elbo_against_the_bound_written_from_the_paper(shape):
     scale = max(abs(r[2]) for r in rows)
     for i, key, f, an in rows:
         assert abs(f - an) < 5e-6 * scale, (i, key, f, an, scale)
+
+
+@pytest.mark.gpu
+def test_adam_steps_from_the_published_formula():
+    """dgp_adam_step against tf.optimizers.Adam's documented update (Kingma & Ba 2015, algorithm 1 in the epsilon-hat form TF uses:
+    m = b1 m + (1 - b1) g, v = b2 v + (1 - b2) g^2, lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), u -= lr_t m / (sqrt(v) + eps)) applied to the
+    UNCONSTRAINED variables behind gpflow's transforms (softplus for kernel variance / lengthscales, softplus + 1e-6 for the noise
+    variance, identity for Z and q_mu, the lower triangle for q_sqrt) - written here from those definitions and carried over four
+    steps with the product's own gradients (themselves held to closed forms above)."""
+    N, D, M, Dy, S = 700, 3, 64, 2, 2
+    m, X, Y, Z, ls = _one_layer_model(N, D, M, Dy, 0.37, S)
+    ctx = m._sync_model()
+    ctx.adam_reset()
+    lr, b1, b2, eps = 0.01, 0.9, 0.999, 1e-7
+    mom = {}
+
+    def to_u(key, x):
+        if key[1] in ("variance", "lengthscales"):
+            return np.log(np.expm1(x - (1e-6 if key[0] == "lik" else 0.0)))
+        return x
+
+    def to_x(key, u):
+        if key[1] in ("variance", "lengthscales"):
+            return np.log1p(np.exp(u)) + (1e-6 if key[0] == "lik" else 0.0)
+        return np.tril(u) if key[1] == "q_sqrt" else u
+    for t in range(1, 5):
+        c = m._grad_step(m.data)
+        G = split_flat(m, c.grad_get())
+        P0 = split_flat(m, ctx.params_get())
+        c.adam_step(lr, b1, b2, eps, m._trainable_flags())
+        P1 = split_flat(m, ctx.params_get())
+        lr_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+        for key in P0:
+            x0, x1, g = np.asarray(P0[key], dtype=float), np.asarray(P1[key], dtype=float), -np.asarray(G[key], dtype=float)   # objective = -ELBO
+            if key[1] in ("variance", "lengthscales"):
+                g = g * (-np.expm1(-(x0 - (1e-6 if key[0] == "lik" else 0.0))))        # dx/du = sigmoid(u) = 1 - exp(-softplus(u))
+            if key[1] == "q_sqrt":
+                g = np.tril(g)
+                assert np.abs(np.triu(x1, 1)).max() == 0.0
+            mm, vv = mom.get(key, (np.zeros_like(g), np.zeros_like(g)))
+            mm = b1 * mm + (1 - b1) * g
+            vv = b2 * vv + (1 - b2) * g * g
+            mom[key] = (mm, vv)
+            want = to_x(key, to_u(key, x0) - lr_t * mm / (np.sqrt(vv) + eps))
+            assert np.abs(x1 - want).max() < 1e-12 * max(1.0, np.abs(want).max()), (t, key)
+            assert np.abs(x1 - x0).max() > 1e-4                 # (every family moves by about lr)
+    m._device_newer = True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gamma", [0.01, 0.3])
+@pytest.mark.parametrize("shape", [(700, 3, 64, 2, 2), (20_000, 8, 256, 1, 2)], ids=["N700_M64_Dy2", "N20000_M256"])
+def test_natural_gradient_step_of_any_size_interpolates_the_natural_parameters(shape, gamma):
+    """For a conjugate model the natural gradient IS the difference of natural parameters to the optimum, so
+    NaturalGradient(gamma).minimize moves q(u)'s natural parameters (S^-1 m, -S^-1 / 2) to (1 - gamma) theta_0 + gamma theta_opt
+    (Hensman et al. 2013, section 3; Salimbeni et al. 2018).  theta_opt from the collapsed bound's closed form (tests/helpers.py):
+    dgp_natgrad_step at the step sizes training uses (0.01) and a large one, without the oracle."""
+    from helpers import collapsed_bound
+    N, D, M, Dy, S = shape
+    noise = 0.37
+    m, X, Y, Z, ls = _one_layer_model(N, D, M, Dy, noise, S)
+    l = m.layers[0]
+    m0, L0 = l.q_mu.numpy().copy(), np.tril(l.q_sqrt.numpy()).copy()
+    _, m_opt, S_opt = collapsed_bound(X, Y, Z, 1.3, ls, noise, 1e-6)
+    mask = m._natgrad_setup(True)
+    c = m._grad_step(m.data)
+    c.natgrad_step(gamma, mask)
+    m._device_newer = True
+    P_opt = np.linalg.inv(S_opt)
+    for d in range(Dy):
+        P0 = np.linalg.inv(L0[d] @ L0[d].T)
+        P_want = (1.0 - gamma) * P0 + gamma * P_opt
+        h_want = (1.0 - gamma) * P0 @ m0[:, d] + gamma * P_opt @ m_opt[:, d]
+        Ld = np.tril(l.q_sqrt.numpy()[d])
+        S_got = Ld @ Ld.T
+        S_want = np.linalg.inv(P_want)
+        assert np.abs(S_got - S_want).max() < 1e-8 * max(1.0, np.abs(S_want).max())
+        assert np.abs(l.q_mu.numpy()[:, d] - S_want @ h_want).max() < 1e-8 * max(1.0, np.abs(S_want @ h_want).max())
