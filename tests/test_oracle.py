@@ -519,3 +519,29 @@ def test_oracle_three_layer_elbo_equals_the_bound_for_any_depth():
     want = dsdgp_elbo(X, Y, zs, lay, 0.25, O.JITTER)
     got = mo.ELBO(zs)
     assert abs(got - want) < 1e-10 * abs(want), (got, want)
+
+
+@pytest.mark.parametrize("gamma", [0.01, 0.3])
+def test_oracle_natural_gradient_step_interpolates_the_natural_parameters(gamma):
+    """The oracle's natgrad_step at any step size against the convex combination of natural parameters a conjugate model requires
+    (see the GPU test of the same name): theta_new = (1 - gamma) theta_0 + gamma theta_opt, theta_opt from the collapsed bound."""
+    from dgp_oracle_train import OracleTrainer
+    from helpers import collapsed_bound
+    N, D, M = 300, 2, 20
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((N, D))
+    Y = np.sin(2 * X[:, :1]) + 0.3 * rng.standard_normal((N, 1))
+    Z = X[:M].copy()
+    ls = np.array([0.8, 1.2])
+    mo = O.OracleDGP(X, Y, Z, [O.RBF(1.3, ls)], [], lik_variance=0.37, num_samples=2)
+    l = mo.layers[0]
+    l.q_mu = 0.1 * rng.standard_normal((M, 1))
+    l.q_sqrt = np.tril(0.3 * np.eye(M) + 0.02 * rng.standard_normal((M, M)))[None]
+    m0, L0 = l.q_mu.copy(), l.q_sqrt[0].copy()
+    OracleTrainer(mo, base_seed=5).natgrad_iteration(gamma, [0])
+    _, m_opt, S_opt = collapsed_bound(X, Y, Z, 1.3, ls, 0.37, O.JITTER)
+    P0, P_opt = np.linalg.inv(L0 @ L0.T), np.linalg.inv(S_opt)
+    S_want = np.linalg.inv((1 - gamma) * P0 + gamma * P_opt)
+    m_want = S_want @ ((1 - gamma) * P0 @ m0 + gamma * P_opt @ m_opt)
+    Ln = np.tril(l.q_sqrt[0])
+    assert np.abs(Ln @ Ln.T - S_want).max() < 1e-9 and np.abs(l.q_mu - m_want).max() < 1e-9
