@@ -215,3 +215,18 @@ def dsdgp_elbo(X, Y, zs, layers, noise, jitter):
                 F = F + mu + np.sqrt(v + jitter) * zs[l][s]
         total += (-0.5 * np.log(2 * np.pi * noise) - 0.5 * ((Y - mu) ** 2 + v) / noise).sum()
     return float(total / S - sum(kls))
+
+
+def sparse_gp_predict_full_cov(X, Y, Z, Xnew, variance, lengthscales, noise, jitter, kind="rbf"):
+    """Full predictive covariance of f at Xnew under the optimal q(u) (Titsias 2009, eq. 6): K** - K*u Kuu^-1 Ku* + K*u Sigma Ku*."""
+    import scipy.linalg as sla
+
+    def k(A, B):
+        return stationary_kernel(A, B, variance, lengthscales, kind)
+    M = Z.shape[0]
+    L = np.linalg.cholesky(k(Z, Z) + jitter * np.eye(M))
+    A = sla.solve_triangular(L, k(Z, X), lower=True) / np.sqrt(noise)
+    LB = np.linalg.cholesky(np.eye(M) + A @ A.T)
+    As = sla.solve_triangular(L, k(Z, Xnew), lower=True)
+    Bs = sla.solve_triangular(LB, As, lower=True)
+    return k(Xnew, Xnew) - As.T @ As + Bs.T @ Bs

@@ -2240,3 +2240,38 @@ def test_natural_gradient_step_of_any_size_interpolates_the_natural_parameters(s
         S_want = np.linalg.inv(P_want)
         assert np.abs(S_got - S_want).max() < 1e-8 * max(1.0, np.abs(S_want).max())
         assert np.abs(l.q_mu.numpy()[:, d] - S_want @ h_want).max() < 1e-8 * max(1.0, np.abs(S_want @ h_want).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(700, 3, 64, 1, 2), (20_000, 8, 256, 1, 2)], ids=["N700_M64", "N20000_M256"])
+def test_input_gradients_and_full_covariance_at_the_optimal_q_against_the_predictive_equations(shape):
+    """SURVEY 8f-1 / 8f-4 against closed forms: at the optimal q(u) of a one-layer model, dgp_propagate_vjp (what replaces
+    tf.GradientTape on x, Infill_criteria.py:79-85) against central differences of Titsias' predictive mean / variance in the candidate
+    inputs, and predict_f(full_cov=True) against the full predictive covariance of the same equations."""
+    from helpers import sparse_gp_predict, sparse_gp_predict_full_cov
+    N, D, M, Dy, S = shape
+    noise = 0.37
+    m, X, Y, Z, ls = _one_layer_model(N, D, M, Dy, noise, S)
+    c = m._grad_step(m.data)
+    c.natgrad_step(1.0, m._natgrad_setup(True))
+    m._device_newer = True
+    rng = np.random.default_rng(21)
+    Xn = rng.standard_normal((23, D))
+    a, b = rng.standard_normal((1, 23, Dy)), rng.standard_normal((1, 23, Dy))
+    gx = np.asarray(m.propagate_vjp(Xn, S=1, mean_bar=a, var_bar=b, zs=[np.zeros((1, 23, Dy))]))
+    assert gx.shape == Xn.shape
+    h = 1e-6
+    for t in range(3):
+        V = rng.standard_normal(Xn.shape)
+        V /= np.linalg.norm(V)
+        f = []
+        for sg in (+1, -1):
+            pm, pv = sparse_gp_predict(X, Y, Z, Xn + sg * h * V, 1.3, ls, noise, 1e-6)
+            f.append(float((a[0] * pm).sum() + (b[0] * pv).sum()))
+        fd = (f[0] - f[1]) / (2 * h)
+        assert abs(fd - float((gx * V).sum())) < 1e-6 * max(1.0, abs(fd)), (t, fd, float((gx * V).sum()))
+    Fm, Fv = m.predict_f(Xn, full_cov=True, S=2)
+    Fv = np.asarray(Fv)
+    want = sparse_gp_predict_full_cov(X, Y, Z, Xn, 1.3, ls, noise, 1e-6)
+    assert Fv.shape == (2, 23, 23, Dy)
+    assert np.abs(Fv[..., 0] - want[None]).max() < 1e-8 * max(1.0, np.abs(want).max())
