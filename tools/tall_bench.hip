@@ -7,7 +7,7 @@
 //         dgp-toolbox_amd/csrc/gemm_f64.hip dgp-toolbox_amd/csrc/gemm_wide.hip dgp-toolbox_amd/csrc/gemm_gram.hip \
 //         dgp-toolbox_amd/csrc/gemm_tall.hip dgp-toolbox_amd/csrc/gemm_tallu.hip dgp-toolbox_amd/csrc/gemm_small.hip \
 //         dgp-toolbox_amd/csrc/gemm_mid.hip -o tools/tall_bench
-//   tools/tall_bench [rows] [reps] [D] [which: bitmask 1 T/NT, 2 T/plain, 4 T/no store, 8 dC, 16 Gram, 32 g row-panel, 64 dC row-panel, 128 Gram two sources]
+//   tools/tall_bench [rows] [reps] [D] [which: bitmask 1 T/NT, 2 T/plain, 4 T/no store, 8 dC, 16 Gram, 32 g row-panel, 64 dC row-panel, 128 Gram two sources, 1024 Ct solve]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -125,6 +125,22 @@ int main(int argc, char** argv) {
         printf("G_d and du_d = sum_p mbar_pd c_p          %8.3f ms  %5.1f TFLOP/s algorithmic\n", t2, flopsT / t2 / 1e9);
       }
     }
+  }
+  if (which & 1024) {
+    // the forward solve  Ct = Kt Linv^T  (upper-triangular B, row sums |c|^2, mean0 = Kt alpha riding on it): what the training step
+    // launches through gemm_f64 (dgp_ctx.h: args_Ct) - the wide-tile kernel <1, false, 4>
+    double* LinvT = dalloc(256 * 256); fill_tri_blocks(LinvT, 256, 256, false, 9);
+    double* alpha = dalloc(256 * D); fill_rand(alpha, 256 * D, 10);
+    double* mean0 = dalloc((size_t)P * D);
+    double* cnp = dalloc((size_t)2 * P);
+    GemmArgs a{};
+    a.A = T; a.lda = 256; a.B = LinvT; a.ldb = 256; a.C = Cb; a.ldc = 256; a.M = P; a.N = 256; a.K = 256; a.batch = 1; a.splits = 1;
+    a.alpha = 1.0; a.beta = 0; a.tri = TRI_B_UPPER; a.triblk = 256; a.epi = 2; a.rowsq = cnp; a.rowsq_ld = P;
+    a.mean_alpha = alpha; a.mean_out = mean0; a.mean_d = D;
+    a.cu_count = cus;
+    const float t = time_ms(st, reps, [&]() { CK(gemm_f64(st, GEMM_NN, a)); });
+    printf("Ct = Kt LinvT (+ |c|^2, mean0)            %8.3f ms  %5.1f TFLOP/s algorithmic; 4.1 GB moved -> %.2f TB/s\n", t, (double)P * 256.0 * 257.0 / t / 1e9,
+           ((double)P * 256 * 8 * 2 + (double)P * D * 8) / t / 1e9);
   }
 #ifdef TL_TIMING
   if (which & 256) {
