@@ -20,8 +20,9 @@ pid=$!; sleep 1.5; sample 5; wait $pid; tail -1 $O/run_copy.txt
 fi
 for v in "16 Gram" "4 T_row_sums_only" "1 T_with_stores" "8 dC_tall_tile" "32 g_row_panel" "1024 Ct_solve"; do
   set -- $v
-  echo "== $2 (tools/tall_bench 1000000 400 8 $1)"
-  timeout -k 10 120 tools/tall_bench 1000000 400 8 $1 > $O/run_$2.txt 2>&1 &
+  reps=400; [ $1 = 32 -o $1 = 1024 ] && reps=2500        # (1.5 - 1.8 ms launches: enough of them to sample beside)
+  echo "== $2 (tools/tall_bench 1000000 $reps 8 $1)"
+  timeout -k 10 120 tools/tall_bench 1000000 $reps 8 $1 > $O/run_$2.txt 2>&1 &
   pid=$!; sleep 1.5; sample 5; wait $pid; tail -1 $O/run_$2.txt
 done
 if [ -x tools/tall_bench_SPREAD ]; then
